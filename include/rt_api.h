@@ -1,0 +1,203 @@
+/*
+ * rt_api.h - C ABI of the MI355X rendering core (librt_hip.so).
+ *
+ * The library replaces one call of the reference:
+ *
+ *   Camera::render(&self, world, depth, single_threaded, output, rng) -> Canvas
+ *       reference src/camera.rs:105-191 (reached from src/scene/mod.rs:92-100
+ *       and src/main.rs:50-55)
+ *
+ * together with everything that call runs per pixel (World::colour_at and
+ * below, src/world.rs:33-177).  The reference has no FFI of its own; these
+ * entry points are what an `extern "C"` block in a Rust `-sys` crate would
+ * bind (the stub is shown in INTEGRATION.md).  All arguments are plain
+ * pointers and sizes.  Every function returns 0 on success and a negative
+ * code otherwise; the message is available from rt_last_error() on the
+ * calling thread.  The caller owns every buffer it passes; the library owns
+ * rt_scene.  Calls on one rt_scene must not overlap.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes */
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)     /* malformed description / argument          */
+#define RT_ERR_HIP (-2)         /* a HIP runtime call failed                 */
+#define RT_ERR_UNSUPPORTED (-3) /* scene uses a feature the device path lacks */
+#define RT_ERR_CAPACITY (-4)    /* a per-ray list overflowed its fixed bound */
+#define RT_ERR_NAN (-5)         /* an intersection distance was NaN (the
+                                   reference panics: src/intersection/list.rs:39-50) */
+
+/* node kinds, shape kinds, csg operations, pattern kinds, light kinds */
+enum { RT_NODE_LEAF = 0, RT_NODE_GROUP = 1, RT_NODE_CSG = 2 };
+enum { RT_SPHERE = 0, RT_PLANE = 1, RT_CUBE = 2, RT_CYLINDER = 3, RT_CONE = 4, RT_TRIANGLE = 5 };
+enum { RT_CSG_DIFFERENCE = 0, RT_CSG_INTERSECTION = 1, RT_CSG_UNION = 2 };
+enum { RT_PAT_SOLID = 0, RT_PAT_STRIPE = 1, RT_PAT_RING = 2, RT_PAT_CHECKER = 3,
+       RT_PAT_GRADIENT = 4, RT_PAT_RADIAL_GRADIENT = 5, RT_PAT_BLEND = 6 };
+enum { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 1 };
+
+#define RT_NONE 0xFFFFFFFFu
+
+/*
+ * Flattened world.  Replaces `World { objects: Vec<Object>, lights }`
+ * (reference src/world.rs:13-16) and the Object tree under it
+ * (src/object/mod.rs:36-40).  All arrays are host pointers and are copied by
+ * rt_scene_create.
+ *
+ * Nodes are listed in depth-first pre-order of the tree whose implicit root
+ * is the world: world.objects in order, each Group's children in stored
+ * order, a Csg's left subtree before its right.  node_skip[i] is the index
+ * of the first node after the subtree of node i, so the children of i are
+ * i+1, node_skip[i+1], ... while < node_skip[i].  Leaves are numbered in the
+ * same order (leaf k is the k-th leaf node met), which makes "smaller leaf
+ * index" the insertion order the reference's stable sorts preserve
+ * (src/world.rs:90-106, src/intersection/list.rs:24-50).
+ */
+typedef struct rt_scene_desc {
+    uint32_t n_nodes;
+    const uint32_t *node_kind; /* RT_NODE_*                                         */
+    const uint32_t *node_skip; /* first node after this subtree                     */
+    const uint32_t *node_arg;  /* leaf: leaf index; csg: csg index; group: unused   */
+    const double *node_bbox;   /* n_nodes*6: min xyz, max xyz of the STORED box of a
+                                  group / csg (src/object/group/mod.rs:20,
+                                  src/object/csg/mod.rs:18); ignored for leaves     */
+
+    uint32_t n_leaves;
+    const uint32_t *leaf_shape;    /* RT_SPHERE ...                                 */
+    const double *leaf_inv;        /* n_leaves*12: rows 0-2 of the inverse
+                                      transformation, row-major (shape.rs:28)       */
+    const double *leaf_param;      /* n_leaves*3: cylinder/cone minimum, maximum,
+                                      closed (0.0 / 1.0); unused otherwise          */
+    const uint32_t *leaf_tri;      /* triangle index or RT_NONE                     */
+    const uint32_t *leaf_class;    /* structural-equality class (shape.rs:108)      */
+    const uint32_t *leaf_material; /* material index                                */
+    const uint8_t *leaf_casts_shadow;
+
+    uint32_t n_tris;
+    const double *tri_data; /* n_tris*18: p1, e1, e2, n1, n2, n3 (triangle.rs:12-21) */
+
+    uint32_t n_csgs;
+    const uint32_t *csg_op;       /* RT_CSG_*                                       */
+    uint32_t n_classes;           /* class ids are < n_classes                      */
+    const uint64_t *csg_left_bits; /* n_csgs * ceil(n_classes/64) words: bit c set
+                                      when some leaf of class c is in the left
+                                      subtree (csg/mod.rs:67 `left.includes`)      */
+
+    uint32_t n_materials;
+    const double *material;          /* n_materials*7: ambient, diffuse, specular,
+                                        shininess, reflective, transparency,
+                                        refractive_index (material.rs:15-32)       */
+    const uint32_t *material_pattern; /* root pattern node of each material        */
+
+    uint32_t n_patterns;
+    const uint32_t *pat_kind; /* RT_PAT_*                                           */
+    const uint32_t *pat_a;    /* child pattern nodes (RT_NONE for solid)            */
+    const uint32_t *pat_b;
+    const double *pat_inv;    /* n_patterns*12: rows 0-2 of the pattern's inverse   */
+    const double *pat_colour; /* n_patterns*3: colour of a solid pattern            */
+
+    uint32_t n_lights;
+    const uint32_t *light_kind; /* RT_LIGHT_*                                       */
+    const double *light_data;   /* n_lights*12: point: position, intensity, 6 unused;
+                                   area: corner, u cell vector, v cell vector,
+                                   intensity (light/area.rs:10-18: u, v already
+                                   divided by the step counts)                     */
+    const uint32_t *light_steps; /* n_lights*2: usteps, vsteps (1, 1 for a point)  */
+} rt_scene_desc;
+
+/* Camera (reference src/camera.rs:23-31): sizes, rows 0-2 of the inverse view
+ * transformation and the three derived scalars of Camera::calculate. */
+typedef struct rt_camera {
+    uint32_t width, height;
+    double inv[12];
+    double half_width, half_height, pixel_size;
+} rt_camera;
+
+/* Which image rows a call renders: rows y with (y / block_rows) % world == rank.
+ * {0, 0, 1} or a NULL pointer selects every row.  block_rows must be a
+ * multiple of 8 when world > 1.  Output buffers then hold only the selected
+ * rows, in increasing y. */
+typedef struct rt_partition {
+    uint32_t block_rows, rank, world;
+} rt_partition;
+
+typedef struct rt_stats {
+    uint64_t primary_rays;   /* one per rendered pixel                              */
+    uint64_t secondary_rays; /* colour_at calls from reflected_/refracted_colour
+                                (src/world.rs:142,175)                             */
+    uint64_t shadow_rays;    /* is_shadowed calls (src/world.rs:109)               */
+    uint64_t shade_hits;     /* shade_hit calls (src/world.rs:52)                  */
+    uint32_t levels;         /* deepest recursion level that held rays, plus one   */
+    uint32_t chunks;         /* row chunks the frame was rendered in               */
+    double ms_total;         /* device time of the whole call                      */
+    double ms_trace;         /* summed time of the per-level trace+shade kernels   */
+    double ms_combine;       /* summed time of the bottom-up combine kernels       */
+    uint64_t trace_launches; /* number of trace+shade kernel launches              */
+    uint64_t algorithmic_flop; /* Σ op-class counts × the per-op constants stated
+                                  in DESIGN.md, counted on the device              */
+} rt_stats;
+
+typedef struct rt_scene rt_scene;
+
+/* Select the HIP device this thread renders on (one process per GPU). */
+int rt_init(int device);
+
+/* Upload a flattened world.  Rejects malformed trees (RT_ERR_INVALID) and
+ * pattern kinds outside RT_PAT_* (RT_ERR_UNSUPPORTED). */
+int rt_scene_create(const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_destroy(rt_scene *scene);
+
+/*
+ * Render.  Replaces Camera::render (src/camera.rs:105-191).
+ *   depth      the `depth` argument (src/arguments.rs:33-35)
+ *   row_seeds  camera->height u64 values: the per-row seeds the reference
+ *              draws from the caller's rng (src/camera.rs:159-161); may be
+ *              NULL when the scene has no area light (no other consumer)
+ *   part       row partition, or NULL for the whole image
+ *   out_rgb    rows*width*3 f64, row-major linear colour (Canvas::pixels,
+ *              src/canvas.rs:7-11), or NULL
+ *   out_rgb8   rows*width*3 bytes of Colour::to_u8 (src/colour.rs:63-72), or NULL
+ *   out_on_device  non-zero when the two output pointers are device memory
+ *   stats      optional
+ */
+int rt_render(rt_scene *scene, const rt_camera *camera, uint32_t depth, const uint64_t *row_seeds,
+              const rt_partition *part, double *out_rgb, uint8_t *out_rgb8, int out_on_device,
+              rt_stats *stats);
+
+/*
+ * World::colour_at for caller-supplied rays (src/world.rs:33-49): n rays of
+ * 6 f64 (origin, direction), host memory; out_rgb n*3 f64, host memory.
+ * Ray i uses an rng seeded with seeds[i] (area lights only; may be NULL).
+ */
+int rt_colour_at(rt_scene *scene, uint32_t n, const double *rays, uint32_t depth,
+                 const uint64_t *seeds, double *out_rgb);
+
+/*
+ * Intersection::prepare_computations for the hit of each ray
+ * (src/intersection/mod.rs:45-109, src/world.rs:90-126).  Per ray 32 f64:
+ *  [0] hit leaf index or -1, [1] t, [2..4] point, [5..7] over_point,
+ *  [8..10] under_point, [11..13] eye, [14..16] normal, [17] inside,
+ *  [18..20] reflect, [21] n1, [22] n2, [23] schlick, [24] number of
+ *  intersections delivered to the world list, [25..28] is_shadowed towards
+ *  the first four lights' positions (area light: its corner) from over_point,
+ *  [29..31] unused.
+ */
+int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
+
+/* Limits of this build (per-ray list bounds). */
+uint32_t rt_max_csg_list(void);       /* intersections inside one outermost csg    */
+uint32_t rt_max_container_list(void); /* intersections at or before a refractive hit */
+
+const char *rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */
