@@ -137,7 +137,8 @@ typedef struct rt_stats {
     uint32_t levels;         /* deepest recursion level that held rays, plus one   */
     uint32_t chunks;         /* row chunks the frame was rendered in               */
     double ms_total;         /* device time of the whole call                      */
-    double ms_trace;         /* summed time of the per-level trace+shade kernels   */
+    double ms_trace;         /* summed HIP-event durations of the per-level
+                                trace+shade kernel launches                         */
     double ms_combine;       /* summed time of the bottom-up combine kernels       */
     uint64_t trace_launches; /* number of trace+shade kernel launches              */
     uint64_t algorithmic_flop; /* Σ op-class counts × the per-op constants stated

@@ -48,8 +48,9 @@ struct NanT {};
 
 // List::sort (intersection/list.rs:39-50): stable; a NaN t panics.
 void sort_list(List& l) {
-    for (const Isect& i : l)
-        if (std::isnan(i.t)) throw NanT();
+    if (l.size() >= 2)  // a one-element sort never calls the comparator
+        for (const Isect& i : l)
+            if (std::isnan(i.t)) throw NanT();
     std::stable_sort(l.begin(), l.end(), [](const Isect& a, const Isect& b) { return a.t < b.t; });
 }
 
@@ -590,6 +591,38 @@ int orc_render_rows(void* h, uint32_t depth, const uint64_t* seeds, uint32_t y0,
         for (int i = 0; i < threads; i++) pool.emplace_back(worker);
         for (auto& t : pool) t.join();
     }
+    if (failed == 1) { g_error = "NaN intersection distance while sorting"; return -5; }
+    if (failed) { g_error = "render failed"; return -1; }
+    return 0;
+}
+
+// The same for an explicit list of rows (each row is complete, so the per-row
+// rng stream is exactly the reference's).  out_rgb holds the rows in list order.
+int orc_render_row_list(void* h, uint32_t depth, const uint64_t* seeds, uint32_t n_rows, const uint32_t* rows,
+                        int threads, double* out_rgb) {
+    auto* s = (OrcScene*)h;
+    const Camera& cam = s->scene.camera;
+    std::atomic<uint32_t> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        for (;;) {
+            uint32_t k = next.fetch_add(1);
+            if (k >= n_rows) break;
+            uint32_t y = rows[k];
+            try {
+                Xoshiro256pp rng = Xoshiro256pp::seed_from_u64(seeds ? seeds[y] : 0);
+                for (uint32_t x = 0; x < cam.hsize; x++) {
+                    V3 c = s->world.colour_at(ray_for_pixel(cam, x, y), depth, rng);
+                    double* px = out_rgb + ((size_t)k * cam.hsize + x) * 3;
+                    px[0] = c.x; px[1] = c.y; px[2] = c.z;
+                }
+            } catch (const NanT&) { failed = 1; }
+            catch (const std::exception&) { failed = 2; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 0; i < std::max(1, threads); i++) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
     if (failed == 1) { g_error = "NaN intersection distance while sorting"; return -5; }
     if (failed) { g_error = "render failed"; return -1; }
     return 0;

@@ -1002,6 +1002,7 @@ struct rt_scene {
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> launch_ev;  // start/stop pairs around every level kernel
     size_t chunk_pixels = (size_t)4 << 20;
     size_t recs_per_pixel = 24;
 };
@@ -1067,6 +1068,12 @@ int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint
         if ((size_t)rec_base + n > s->rec_cap) { *overflow = true; return RT_ERR_CAPACITY; }
         level_base.push_back(rec_base);
         level_n.push_back(n);
+        while (s->launch_ev.size() < 2 * ((size_t)level + 1)) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            s->launch_ev.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(s->launch_ev[2 * level], 0));
         if (primary && level == 0) {
             uint32_t waves = A.n_tiles;
             uint32_t blocks = (waves + 3) / 4;
@@ -1077,6 +1084,7 @@ int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint
         }
         tot.launches++;
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->launch_ev[2 * level + 1], 0));
         HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
         HIP_TRY(hipStreamSynchronize(0));
         uint32_t next = s->counters_host->next_count;
@@ -1107,8 +1115,10 @@ int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint
     HIP_TRY(hipEventRecord(s->ev[2], 0));
     HIP_TRY(hipStreamSynchronize(0));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
-    tot.ms_trace += ms;
+    for (size_t level = 0; level < level_n.size(); level++) {
+        HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[2 * level], s->launch_ev[2 * level + 1]));
+        tot.ms_trace += ms;
+    }
     HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
     tot.ms_combine += ms;
     tot.secondary += s->counters_host->secondary;
@@ -1268,6 +1278,7 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->stage_rgb) (void)hipFree(s->stage_rgb);
     if (s->stage_rgb8) (void)hipFree(s->stage_rgb8);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->launch_ev) if (e) (void)hipEventDestroy(e);
     delete s;
 }
 

@@ -37,6 +37,7 @@ def lib():
         L.orc_row_seeds.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_render_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_render_row_list.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_colour_at.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
@@ -100,6 +101,14 @@ class OracleScene:
         y1 = self.height if y1 is None else y1
         out = np.zeros((y1 - y0, self.width, 3), dtype=np.float64)
         rc = lib().orc_render_rows(self.h, depth, _ptr(seeds), y0, y1, threads, _ptr(out))
+        if rc != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return out
+
+    def render_row_list(self, depth, rows, seeds=None, threads=8):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.zeros((rows.shape[0], self.width, 3), dtype=np.float64)
+        rc = lib().orc_render_row_list(self.h, depth, _ptr(seeds), rows.shape[0], _ptr(rows), threads, _ptr(out))
         if rc != 0:
             raise RuntimeError(lib().orc_last_error().decode())
         return out
