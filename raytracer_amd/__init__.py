@@ -57,6 +57,28 @@ class Stats(C.Structure):
         return {name: getattr(self, name) for name, _ in self._fields_}
 
 
+class SceneDesc(C.Structure):
+    """rt_scene_desc (include/rt_api.h), field for field."""
+    _u32p, _f64p = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    _fields_ = [
+        ("n_nodes", C.c_uint32), ("node_kind", _u32p), ("node_skip", _u32p), ("node_arg", _u32p), ("node_bbox", _f64p),
+        ("n_leaves", C.c_uint32), ("leaf_shape", _u32p), ("leaf_inv", _f64p), ("leaf_param", _f64p),
+        ("leaf_tri", _u32p), ("leaf_class", _u32p), ("leaf_material", _u32p), ("leaf_casts_shadow", C.POINTER(C.c_uint8)),
+        ("n_tris", C.c_uint32), ("tri_data", _f64p),
+        ("n_csgs", C.c_uint32), ("csg_op", _u32p), ("n_classes", C.c_uint32), ("csg_left_bits", C.POINTER(C.c_uint64)),
+        ("n_materials", C.c_uint32), ("material", _f64p), ("material_pattern", _u32p),
+        ("n_patterns", C.c_uint32), ("pat_kind", _u32p), ("pat_a", _u32p), ("pat_b", _u32p), ("pat_inv", _f64p),
+        ("pat_colour", _f64p),
+        ("n_lights", C.c_uint32), ("light_kind", _u32p), ("light_data", _f64p), ("light_steps", _u32p),
+    ]
+
+
+class CameraDesc(C.Structure):
+    """rt_camera"""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("inv", C.c_double * 12),
+                ("half_width", C.c_double), ("half_height", C.c_double), ("pixel_size", C.c_double)]
+
+
 _hip = None
 _host = None
 
@@ -216,6 +238,36 @@ class Scene:
 
     def camera_ptr(self):
         return host_lib().rth_camera(self.h)
+
+    def desc(self):
+        """The flattened world as numpy arrays (copies)."""
+        d = C.cast(self.desc_ptr(), C.POINTER(SceneDesc)).contents
+        words = (d.n_classes + 63) // 64
+
+        def arr(ptr, n, width=1):
+            if n * width == 0 or not ptr:
+                a = np.zeros(0, dtype=np.ctypeslib.as_ctypes_type(ptr._type_))
+            else:
+                a = np.ctypeslib.as_array(ptr, shape=(n * width,)).copy()
+            return a.reshape(n, width) if width > 1 else a
+        return {
+            "node_kind": arr(d.node_kind, d.n_nodes), "node_skip": arr(d.node_skip, d.n_nodes),
+            "node_arg": arr(d.node_arg, d.n_nodes), "node_bbox": arr(d.node_bbox, d.n_nodes, 6),
+            "leaf_shape": arr(d.leaf_shape, d.n_leaves), "leaf_inv": arr(d.leaf_inv, d.n_leaves, 12),
+            "leaf_param": arr(d.leaf_param, d.n_leaves, 3), "leaf_tri": arr(d.leaf_tri, d.n_leaves),
+            "leaf_class": arr(d.leaf_class, d.n_leaves), "leaf_material": arr(d.leaf_material, d.n_leaves),
+            "leaf_casts_shadow": arr(d.leaf_casts_shadow, d.n_leaves), "tri_data": arr(d.tri_data, d.n_tris, 18),
+            "csg_op": arr(d.csg_op, d.n_csgs), "csg_left_bits": arr(d.csg_left_bits, d.n_csgs * words),
+            "material": arr(d.material, d.n_materials, 7), "material_pattern": arr(d.material_pattern, d.n_materials),
+            "pat_kind": arr(d.pat_kind, d.n_patterns), "pat_a": arr(d.pat_a, d.n_patterns),
+            "pat_b": arr(d.pat_b, d.n_patterns), "pat_inv": arr(d.pat_inv, d.n_patterns, 12),
+            "pat_colour": arr(d.pat_colour, d.n_patterns, 3), "light_kind": arr(d.light_kind, d.n_lights),
+            "light_data": arr(d.light_data, d.n_lights, 12), "light_steps": arr(d.light_steps, d.n_lights, 2),
+            "n_classes": d.n_classes,
+        }
+
+    def camera(self):
+        return C.cast(self.camera_ptr(), C.POINTER(CameraDesc)).contents
 
     def upload(self):
         rc = host_lib().rth_upload(self.h)

@@ -1,0 +1,84 @@
+"""The CPU oracle against the reference's own known answers (no GPU needed)."""
+import numpy as np
+
+import common_cases as cc
+import known_answers as ka
+import oracle_lib as ol
+
+
+def make(text):
+    return ol.OracleScene.from_text(text)
+
+
+def test_colour_known_answers():
+    cc.check_colours(make)
+
+
+def test_n1_n2_table():
+    cc.check_n1_n2(make)
+
+
+def test_schlick():
+    cc.check_schlick(make)
+
+
+def test_shape_intersections_and_normals():
+    cc.check_shapes(make)
+
+
+def test_prepare_computations():
+    cc.check_prepare(make)
+
+
+def test_camera_rays():  # camera.rs:265-366
+    for view, (x, y), origin, direction in ka.CAMERA_CASES:
+        s = make(ka.camera_scene(view))
+        r = s.ray_for_pixel(x, y)
+        assert np.allclose(r[:3], origin, atol=1e-12) and np.allclose(r[3:], direction, atol=1e-5), r
+    # transformed camera: view = rotate_y(pi/4) * translate(0,-2,5) is not expressible in the scene format; the
+    # render of world::test_world through the 11x11 camera covers view_transformation instead (world.rs:555-577)
+    s = make(ka.TEST_WORLD)
+    px = s.render_pixels(5, np.array([[5, 5]], dtype=np.uint32))[0]
+    assert np.allclose(px, (0.38066, 0.47583, 0.2855), atol=1e-5)
+    multi = s.render_rows(5, None, threads=4)  # world.rs:579-600: same pixel from the threaded path
+    assert np.array_equal(multi[5, 5], px)
+
+
+def test_rng_known_answers():
+    # light/area.rs:136-160 with Area::new(origin, (2,0,0), 4, z, 2): cells (0.5,0,0) and (0,0,0.5)
+    r = ol.rng_gen_range(0, 10)
+    k = 0
+    for (u, v), (x, z) in ka.AREA_POINTS:
+        px = 0.5 * (u + r[k]); pz = 0.5 * (v + r[k + 1]); k += 2
+        assert abs(px - x) < 1e-5 and abs(pz - z) < 1e-5, (u, v, px, pz)
+    # xoshiro256++ reference vector (state 1,2,3,4 is not reachable through seed_from_u64; check determinism and
+    # the SplitMix64 seeding against the published first output of SplitMix64(0))
+    a, b = ol.rng_u64(0, 4), ol.rng_u64(0, 4)
+    assert (a == b).all() and len(set(a.tolist())) == 4
+    assert (ol.rng_gen_range(7, 1000, -5.0, 5.0) <= 5.0).all() and (ol.rng_gen_range(7, 1000, -5.0, 5.0) >= -5.0).all()
+
+
+def test_area_light_intensity_sequence():
+    # light/area.rs:164-198: 2x2 area light over world::test_world, one rng for five successive calls.  The oracle's
+    # colour path draws the same stream; here the first call (point (0,0,2), fully shadowed -> 0.0) and the last
+    # (point (0,0,-2), fully lit -> 1.0) are checked through is_shadowed towards the light corner.
+    text = ka.CAMERA + """
+- add: light
+  corner: [-0.5, -0.5, -5]
+  uvec: [1, 0, 0]
+  usteps: 2
+  vvec: [0, 1, 0]
+  vsteps: 2
+  intensity: [1, 1, 1]
+""" + ka.OUTER + ka.INNER
+    s = make(text)
+    # a ray that hits the outer sphere at (0,0,1) from behind: over_point ~ (0,0,1+): in shadow of the sphere itself
+    p = s.probe(np.array([[0, 0, 5, 0, 0, -1]], dtype=np.float64))[0]
+    assert p[0] == 0 and p[25] == 1.0
+    p = s.probe(np.array([[0, 0, -5, 0, 0, 1]], dtype=np.float64))[0]
+    assert p[0] == 0 and p[25] == 0.0
+
+
+def test_to_u8():  # colour.rs:133-139
+    v = np.array([[0, 0, 0], [1, 1, 1], [1, 0.5, 0], [-0.5, 1.5, 0.4], [np.nan, 0.5, 0.002]], dtype=np.float64)
+    assert ol.to_u8(v).tolist() == [[0, 0, 0], [255, 255, 255], [255, 128, 0], [0, 255, 102], [0, 128, 1]]
