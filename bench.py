@@ -152,24 +152,30 @@ def main():
             "published_cpu_reference": {"rayon_s": 71.55, "single_thread_s": 264.26, "hardware": "unstated (README.md:120-126)"},
         }
         if world == 1:
-            flop = stats["algorithmic_flop"]
+            flop = stats["flop_trace"]
             ms_k = stats["ms_trace"]
             launches = stats["trace_launches"]
             achieved = flop / (ms_k * 1e-3) / 1e12 if ms_k > 0 else 0.0
-            # algorithmic bytes: 64 B queue write + 64 B queue read per secondary ray, 64 B node record per ray,
-            # f64 + u8 frame buffer per pixel
-            alg_bytes = 128 * secondary + 64 * (primary + secondary) + 27 * primary
+            # algorithmic bytes: 64 B queue write + 64 B queue read per secondary ray, 64 B node record and 80 B
+            # shading record per ray, f64 + u8 frame buffer per pixel
+            alg_bytes = 128 * secondary + (64 + 80) * (primary + secondary) + 27 * primary
             out["roofline"] = {
                 "bound": "valu_fp64",
-                "kernel": "k_level (trace+shade, one launch per recursion level and chunk)",
+                "kernel": "k_trace (closest hit + n1/n2 + spawn; one launch per recursion level and chunk)",
                 "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                 "launches_per_frame": launches,
                 "avg_launch_ms": ms_k / launches if launches else None,
+                "algorithmic_flop_per_launch": flop / launches if launches else None,
                 "algorithmic_flop_per_frame": flop,
                 "kernel_ms_per_frame": ms_k,
-                "combine_ms_per_frame": stats["ms_combine"],
                 "traffic": None,
+                "other_kernels": {
+                    "k_shadow": {"ms_per_frame": stats["ms_shadow"], "algorithmic_flop_per_frame": stats["flop_shadow"],
+                                 "achieved_TFLOPs": stats["flop_shadow"] / (stats["ms_shadow"] * 1e-3) / 1e12 if stats["ms_shadow"] > 0 else 0.0},
+                    "k_light": {"ms_per_frame": stats["ms_light"], "algorithmic_flop_per_frame": stats["flop_light"]},
+                    "k_combine": {"ms_per_frame": stats["ms_combine"]},
+                },
                 "hbm": {"algorithmic_bytes_per_frame": alg_bytes,
                         "achieved_GBs_over_frame": alg_bytes / (ms_per_step * 1e-3) / 1e9,
                         "peak_GBs": HBM_PEAK_GBS},

@@ -137,12 +137,17 @@ typedef struct rt_stats {
     uint32_t levels;         /* deepest recursion level that held rays, plus one   */
     uint32_t chunks;         /* row chunks the frame was rendered in               */
     double ms_total;         /* device time of the whole call                      */
-    double ms_trace;         /* summed HIP-event durations of the per-level
-                                trace+shade kernel launches                         */
-    double ms_combine;       /* summed time of the bottom-up combine kernels       */
-    uint64_t trace_launches; /* number of trace+shade kernel launches              */
-    uint64_t algorithmic_flop; /* Σ op-class counts × the per-op constants stated
-                                  in DESIGN.md, counted on the device              */
+    double ms_trace;         /* summed HIP-event durations of the k_trace launches
+                                (closest hit + n1/n2 + spawn, one per level)       */
+    double ms_shadow;        /* k_shadow launches (shadow rays, one per chunk)     */
+    double ms_light;         /* k_light launches (patterns + Phong, one per chunk) */
+    double ms_combine;       /* the bottom-up fold                                 */
+    uint64_t trace_launches; /* number of k_trace launches                         */
+    uint64_t flop_trace;     /* algorithmic f64 FLOP counted on the device in
+                                k_trace / k_shadow / k_light: op-class counts x the
+                                per-op constants stated in DESIGN.md               */
+    uint64_t flop_shadow;
+    uint64_t flop_light;
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

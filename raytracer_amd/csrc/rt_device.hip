@@ -1,16 +1,26 @@
 // MI355X (gfx950) rendering core: the device side of include/rt_api.h.
 //
 // One launch per recursion level.  A level kernel takes one ray per lane
-// (level 0 builds it from the pixel, deeper levels read a ray queue), walks
-// the flattened object tree as a wavefront (the node index is wave-uniform,
-// node and leaf records arrive through scalar loads, each lane carries a
-// "skip until" index for the subtrees its own bounding-box tests rejected),
-// keeps the closest hit in registers, shades it (shadow rays walk the same
-// tree), writes one 64-byte node record and appends the reflected / refracted
-// rays to the next level's queue with one atomic per wave.  After the last
-// level a bottom-up pass folds the records into colours with exactly the
-// association order of the recursive reference:
+// (level 0 builds it from the pixel, deeper levels read a ray queue) and runs
+// a short list of "jobs" through ONE copy of the tree walk: closest hit of the
+// ray, (for refractive hits) the intersections that precede the hit, then one
+// shadow ray per light sample.  The walk is a wavefront walk: the position in
+// the node stream is wave-uniform and only grows, each node record arrives
+// with one burst of scalar loads (so transforms and boxes sit in SGPRs), and
+// each lane carries a "skip until" position for the subtrees its own box tests
+// rejected.  The closest hit stays in registers.  The lane then writes one
+// 64-byte node record and appends the reflected / refracted rays to the next
+// level's queue with one atomic per wave.  After the last level a bottom-up
+// pass folds the records into colours with exactly the association order of
+// the recursive reference:
 //   surface + reflected * reflectance + refracted * (1 - reflectance).
+//
+// Scenes with area lights take a deferred route, because the reference threads
+// one rng stream through a whole image row in depth-first order: the level
+// kernels only trace (ray paths never depend on the rng), a few small passes
+// number the shade points of each row in the reference's order and step the
+// row's generator to each of them, then one kernel shades every point with
+// its own generator state.
 //
 // All arithmetic is f64 with contraction off; expressions keep the operand
 // order of the reference (cited per function, paths relative to the
@@ -23,6 +33,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -38,6 +49,12 @@ constexpr int CSG_DEPTH = 6;       // nested csg levels
 constexpr int CONT_CAP = 32;       // intersections at or before a refractive hit
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
+#ifndef LEVEL_WAVES_PER_SIMD
+#define LEVEL_WAVES_PER_SIMD 2
+#endif
+#ifndef TRACE_BLOCK
+#define TRACE_BLOCK 256   // threads per k_trace block: one queue-append atomic per block
+#endif
 
 #define DEV __device__ __forceinline__
 #define CADDR __attribute__((address_space(4)))
@@ -79,14 +96,24 @@ DEV V3 reflect(V3 v, V3 n) { return v - (n * 2.0) * dot(v, n); }  // math/vector
 struct Ray { V3 o, d; };
 
 // ---------------------------------------------------------------- device scene
+// The tree is one stream of 64-byte units in depth-first order.  A record
+// starts with four dwords:
+//   w0  kind (bits 0-7: RT_SPHERE..RT_TRIANGLE, K_GROUP, K_CSG) | casts_shadow << 8 | closed << 9
+//   w1  group / csg: unit position of the first record after the subtree; leaf: material index
+//   w2  leaf index / csg index
+//   w3  leaf: structural-equality class
+// followed by
+//   group / csg (1 unit):  stored box, 6 f64
+//   sphere .. cone (2 units): inverse rows 0-2 (12 f64), minimum, maximum
+//   triangle (2 units): w4 transform id, w5 triangle index, then p1, e1, e2 (9 f64 from dword 8);
+//       its inverse lives in `xform` (meshes share one matrix, so a wave transforms its rays once
+//       per matrix, not once per triangle) and its vertex normals in `tri_normals`.
+constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 struct DevScene {
-    uint32_t n_nodes, n_leaves, n_lights, class_words;
-    const uint32_t* node_meta;  // n_nodes*4: kind, skip, arg, 0
-    const double* node_bbox;    // n_nodes*6
-    const double* leaf_inv;     // n_leaves*12
-    const double* leaf_prm;     // n_leaves*4: minimum, maximum, closed, 0
-    const uint32_t* leaf_meta;  // n_leaves*4: shape, tri, material, class | casts_shadow<<31
-    const double* tri;          // n_tris*18
+    uint32_t n_units, n_lights, class_words, draws_per_shade;
+    const uint32_t* stream;
+    const double* xform;        // n_xforms*12
+    const double* tri_normals;  // n_tris*9
     const uint32_t* csg_op;
     const uint64_t* csg_bits;
     const double* mat;          // n_materials*8: 7 scalars, pattern root (as integer value)
@@ -112,11 +139,43 @@ DEV uint32_t wave_min_u32(uint32_t v) {
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
-DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 DEV uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, WAVE);
     return v;
+}
+
+// ---------------------------------------------------------------- rng
+// Xoshiro256PlusPlus of rand_xoshiro 0.6.0 and gen_range(0.0..=1.0) of rand 0.8.5
+// (third-party crates of the reference; call sites camera.rs:144, light/area.rs:50-51).
+struct Rng { unsigned long long s0, s1, s2, s3; };
+DEV unsigned long long rotl64(unsigned long long x, int k) { return (x << k) | (x >> (64 - k)); }
+DEV Rng rng_seed(unsigned long long state) {
+    unsigned long long s[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // SplitMix64
+        state += 0x9e3779b97f4a7c15ULL;
+        unsigned long long z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+        s[i] = z ^ (z >> 31);
+    }
+    Rng r; r.s0 = s[0]; r.s1 = s[1]; r.s2 = s[2]; r.s3 = s[3];
+    return r;
+}
+DEV unsigned long long rng_next(Rng& r) {
+    unsigned long long result = rotl64(r.s0 + r.s3, 23) + r.s0;
+    unsigned long long t = r.s1 << 17;
+    r.s2 ^= r.s0; r.s3 ^= r.s1; r.s1 ^= r.s2; r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = rotl64(r.s3, 45);
+    return result;
+}
+// UniformFloat<f64>::new_inclusive(0.0, 1.0).sample(): scale = 1 / (1 - 2^-52) = 1 + 2^-52 exactly representable
+DEV double rng_unit(Rng& r) {
+    unsigned long long bits = (rng_next(r) >> 12) | 0x3FF0000000000000ULL;
+    double v = __longlong_as_double((long long)bits) - 1.0;
+    return v * 0x1.0000000000001p+0 + 0.0;
 }
 
 // ---------------------------------------------------------------- boxes and shapes
@@ -147,11 +206,16 @@ DEV bool box_intersect(const Ray& r, double x0, double y0, double z0, double x1,
 
 struct LeafHits { int n; double t[4]; };
 
-// Ray into object space (object/shape.rs:49-57, math/transformation/matrix.rs:279-318);
-// the direction is not renormalised.
-DEV Ray to_object_u(const DevScene& S, uint32_t leaf, const Ray& r) {  // leaf wave-uniform
-    const double* m = S.leaf_inv;
-    uint32_t b = leaf * 12;
+DEV V3 mul_point_v(const double* m, V3 p) {  // math/transformation/matrix.rs:279-298
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+DEV V3 mul_vector_v(const double* m, V3 v) {  // matrix.rs:308-318
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+// Ray into object space with a wave-uniform matrix (object/shape.rs:49-57); the direction is not renormalised.
+DEV Ray to_object_u(const double* m, uint32_t b, const Ray& r) {
     Ray o;
     o.o.x = cld(m, b + 0) * r.o.x + cld(m, b + 1) * r.o.y + cld(m, b + 2) * r.o.z + cld(m, b + 3);
     o.o.y = cld(m, b + 4) * r.o.x + cld(m, b + 5) * r.o.y + cld(m, b + 6) * r.o.z + cld(m, b + 7);
@@ -160,14 +224,6 @@ DEV Ray to_object_u(const DevScene& S, uint32_t leaf, const Ray& r) {  // leaf w
     o.d.y = cld(m, b + 4) * r.d.x + cld(m, b + 5) * r.d.y + cld(m, b + 6) * r.d.z;
     o.d.z = cld(m, b + 8) * r.d.x + cld(m, b + 9) * r.d.y + cld(m, b + 10) * r.d.z;
     return o;
-}
-DEV V3 mul_point_v(const double* m, V3 p) {  // per-lane matrix pointer
-    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
-              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
-}
-DEV V3 mul_vector_v(const double* m, V3 v) {
-    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
-              m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
 
 // The six primitives in object space; t values in the reference's emit order.
@@ -266,99 +322,66 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
     return true;
 }
 
-// All intersections of one leaf (wave-uniform leaf index) with the lane's ray.
-DEV void leaf_hits_u(const DevScene& S, uint32_t leaf, const Ray& world, LeafHits& h, uint32_t& flops, bool count) {
-    h.n = 0;
-    uint32_t shape = clu(S.leaf_meta, leaf * 4 + 0);
-    Ray r = to_object_u(S, leaf, world);
-    uint32_t f = F_XFORM;
-    switch (shape) {
-        case RT_SPHERE: sphere_hits(r, h); f += F_SPHERE; break;
-        case RT_PLANE: plane_hits(r, h); f += F_PLANE; break;
-        case RT_CUBE: cube_hits(r, h); f += F_BOX; break;
-        case RT_CYLINDER:
-            cylinder_hits(r, cld(S.leaf_prm, leaf * 4), cld(S.leaf_prm, leaf * 4 + 1), cld(S.leaf_prm, leaf * 4 + 2) != 0.0, h);
-            f += F_CYL;
-            break;
-        case RT_CONE:
-            cone_hits(r, cld(S.leaf_prm, leaf * 4), cld(S.leaf_prm, leaf * 4 + 1), cld(S.leaf_prm, leaf * 4 + 2) != 0.0, h);
-            f += F_CONE;
-            break;
-        default: {  // RT_TRIANGLE
-            uint32_t tb = clu(S.leaf_meta, leaf * 4 + 1) * 18;
-            V3 p1 = mk(cld(S.tri, tb + 0), cld(S.tri, tb + 1), cld(S.tri, tb + 2));
-            V3 e1 = mk(cld(S.tri, tb + 3), cld(S.tri, tb + 4), cld(S.tri, tb + 5));
-            V3 e2 = mk(cld(S.tri, tb + 6), cld(S.tri, tb + 7), cld(S.tri, tb + 8));
-            double t, u, v;
-            if (triangle_hit(r, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
-            f += F_TRI;
-            break;
-        }
-    }
-    if (count) flops += f;
-}
-
-// ---------------------------------------------------------------- sinks
+// ---------------------------------------------------------------- the tree walk
 // What the reference does with the sorted world list, restated for a stream
 // of intersections that arrive in insertion order (world.objects order, group
 // children in stored order, a csg's filtered list in its sorted order):
 //  * List::hit (intersection/list.rs:24-32) = first minimum among t > 0, so a
 //    strict `<` against the running best keeps the reference's tie-break;
 //  * the container walk (intersection/mod.rs:62-94) needs every intersection
-//    that sorts before the hit; ContSink collects them in a second walk.
-struct HitSink {
+//    that sorts before the hit; a second walk (collect = true) gathers them.
+struct Walk {
+    // closest hit so far
     double t;
-    uint32_t leaf;
+    uint32_t pos;          // unit position of the hit leaf's record, or NONE
     uint32_t arrival, hit_arrival;
     bool nan_seen;
-    DEV void init() { t = 0.0; leaf = NONE; arrival = 0; hit_arrival = 0; nan_seen = false; }
-    DEV void emit(bool on, double tt, uint32_t lf) {
-        if (on) {
-            if (tt != tt) nan_seen = true;
-            if (tt > 0.0 && (leaf == NONE || tt < t)) { t = tt; leaf = lf; hit_arrival = arrival; }
-            arrival++;
-        }
-    }
-};
-struct ContSink {
+    // collect mode
     double hit_t;
-    uint32_t hit_arrival, arrival;
+    uint32_t want_arrival;
     int n;
     bool overflow;
-    double* ts;      // CONT_CAP entries (lane-private)
-    uint32_t* leafs;
-    DEV void emit(bool on, double tt, uint32_t lf) {
-        if (on) {
-            if (tt < hit_t || (tt == hit_t && arrival < hit_arrival)) {
-                if (n < CONT_CAP) { ts[n] = tt; leafs[n] = lf; n++; } else overflow = true;
-            }
-            arrival++;
-        }
-    }
 };
 
-// ---------------------------------------------------------------- traversal
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
-// object/csg/mod.rs:57-106).  `i` is wave-uniform and only grows; a lane whose
-// box test fails sets skip_until to the end of that subtree.
-template <bool HAS_CSG, class Sink>
-DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, Sink& sink, uint32_t& flops, bool count,
-                  uint32_t& err) {
+// object/csg/mod.rs:57-106).  `collect` is wave-uniform.
+template <bool HAS_CSG>
+DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect, Walk& w, double* cont_t,
+                  uint32_t* cont_pos, uint32_t& flops, bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
-    const uint32_t n = S.n_nodes;
+    const uint32_t n = S.n_units;
+    const double* streamd = (const double*)S.stream;
     // lane-private csg state (only instantiated for scenes that have a csg)
     double ct[HAS_CSG ? CSG_CAP : 1];
     uint32_t cl[HAS_CSG ? CSG_CAP : 1];
     uint32_t cs_end[HAS_CSG ? CSG_DEPTH : 1], cs_csg[HAS_CSG ? CSG_DEPTH : 1];
     int cs_start[HAS_CSG ? CSG_DEPTH : 1];
     int clen = 0, cs_top = 0;
-    (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen;
+    (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
+
+    auto emit = [&](bool on, double tt, uint32_t p) {
+        if (on) {
+            if (collect) {
+                if (tt < w.hit_t || (tt == w.hit_t && w.arrival < w.want_arrival)) {
+                    if (w.n < CONT_CAP) { cont_t[w.n] = tt; cont_pos[w.n] = p; w.n++; } else w.overflow = true;
+                }
+            } else {
+                if (tt != tt) w.nan_seen = true;
+                if (tt > 0.0 && (w.pos == NONE || tt < w.t)) { w.t = tt; w.pos = p; w.hit_arrival = w.arrival; }
+            }
+            w.arrival++;
+        }
+    };
+
+    // object-space ray of the mesh matrix most recently used (triangles)
+    uint32_t cur_xform = NONE;
+    Ray tri_ray = ray;
 
     uint32_t i = 0;
     for (;;) {
         if constexpr (HAS_CSG) {
-            // Close every csg whose subtree ends at or before node i.
+            // Close every csg whose subtree ends at or before position i.
             while (cs_top > 0 && cs_end[cs_top - 1] <= i) {
                 cs_top--;
                 int start = cs_start[cs_top];
@@ -377,22 +400,22 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, Sink& sink, u
                 uint32_t op = S.csg_op[csg];
                 const uint64_t* bits = S.csg_bits + (size_t)csg * S.class_words;
                 bool in_left = false, in_right = false;
-                int w = start;
+                int wr = start;
                 for (int a = start; a < clen; a++) {
-                    uint32_t cls = S.leaf_meta[cl[a] * 4 + 3] & 0x7FFFFFFFu;
+                    uint32_t cls = S.stream[(size_t)cl[a] * 16 + 3];
                     bool left_hit = (bits[cls >> 6] >> (cls & 63)) & 1ull;
                     bool allowed;
                     if (op == RT_CSG_DIFFERENCE) allowed = (left_hit && !in_right) || (!left_hit && in_left);
                     else if (op == RT_CSG_INTERSECTION) allowed = (left_hit && in_right) || (!left_hit && in_left);
                     else allowed = (left_hit && !in_right) || (!left_hit && !in_left);
-                    if (allowed) { ct[w] = ct[a]; cl[w] = cl[a]; w++; }
+                    if (allowed) { ct[wr] = ct[a]; cl[wr] = cl[a]; wr++; }
                     if (left_hit) in_left = !in_left; else in_right = !in_right;
                 }
                 if (cs_top == 0) {
-                    for (int a = start; a < w; a++) sink.emit(true, ct[a], cl[a]);
+                    for (int a = start; a < wr; a++) emit(true, ct[a], cl[a]);
                     clen = start;
                 } else {
-                    clen = w;
+                    clen = wr;
                 }
             }
         }
@@ -403,37 +426,21 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, Sink& sink, u
             if (i > n) i = n;
             continue;
         }
-        uint32_t kind = clu(S.node_meta, i * 4 + 0);
-        if (kind == RT_NODE_LEAF) {
-            uint32_t leaf = clu(S.node_meta, i * 4 + 2);
-            LeafHits h;
-            leaf_hits_u(S, leaf, ray, h, flops, act && count);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                bool on = act && k < h.n;
-                if constexpr (HAS_CSG) {
-                    if (on && cs_top > 0) {
-                        if (clen < CSG_CAP) { ct[clen] = h.t[k]; cl[clen] = leaf; clen++; } else err |= 2u;
-                        on = false;
-                    }
-                }
-                sink.emit(on, h.t[k], leaf);
-            }
-            i++;
-        } else {
+        const uint32_t w0 = clu(S.stream, i * 16 + 0);
+        const uint32_t kind = w0 & 0xFFu;
+        if (kind >= K_GROUP) {
             // Group or csg: cull by the stored box (group/mod.rs:30-32, csg/mod.rs:89-91)
             double t0, t1;
-            bool hit = box_intersect(ray, cld(S.node_bbox, i * 6 + 0), cld(S.node_bbox, i * 6 + 1),
-                                     cld(S.node_bbox, i * 6 + 2), cld(S.node_bbox, i * 6 + 3),
-                                     cld(S.node_bbox, i * 6 + 4), cld(S.node_bbox, i * 6 + 5), t0, t1);
+            bool hit = box_intersect(ray, cld(streamd, i * 8 + 2), cld(streamd, i * 8 + 3), cld(streamd, i * 8 + 4),
+                                     cld(streamd, i * 8 + 5), cld(streamd, i * 8 + 6), cld(streamd, i * 8 + 7), t0, t1);
             if (act && count) flops += F_BOX;
-            uint32_t end = clu(S.node_meta, i * 4 + 1);
+            uint32_t end = clu(S.stream, i * 16 + 1);
             if (act && !hit) skip_until = end;
             if constexpr (HAS_CSG) {
-                if (kind == RT_NODE_CSG && act && hit) {
+                if (kind == K_CSG && act && hit) {
                     if (cs_top < CSG_DEPTH) {
                         cs_end[cs_top] = end;
-                        cs_csg[cs_top] = clu(S.node_meta, i * 4 + 2);
+                        cs_csg[cs_top] = clu(S.stream, i * 16 + 2);
                         cs_start[cs_top] = clen;
                         cs_top++;
                     } else {
@@ -442,46 +449,116 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, Sink& sink, u
                     }
                 }
             }
-            i++;
+            i += 1;
+            continue;
         }
+        // a leaf
+        LeafHits h;
+        h.n = 0;
+        uint32_t f = F_XFORM;
+        if (kind == RT_TRIANGLE) {
+            uint32_t xf = clu(S.stream, i * 16 + 4);
+            if (xf != cur_xform) {  // wave-uniform: one transform per mesh matrix
+                cur_xform = xf;
+                tri_ray = to_object_u(S.xform, xf * 12, ray);
+            }
+            V3 p1 = mk(cld(streamd, i * 8 + 4), cld(streamd, i * 8 + 5), cld(streamd, i * 8 + 6));
+            V3 e1 = mk(cld(streamd, i * 8 + 7), cld(streamd, i * 8 + 8), cld(streamd, i * 8 + 9));
+            V3 e2 = mk(cld(streamd, i * 8 + 10), cld(streamd, i * 8 + 11), cld(streamd, i * 8 + 12));
+            double t, u, v;
+            if (triangle_hit(tri_ray, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
+            f += F_TRI;
+        } else {
+            Ray r = to_object_u(streamd, i * 8 + 2, ray);
+            if (kind == RT_SPHERE) { sphere_hits(r, h); f += F_SPHERE; }
+            else if (kind == RT_PLANE) { plane_hits(r, h); f += F_PLANE; }
+            else if (kind == RT_CUBE) { cube_hits(r, h); f += F_BOX; }
+            else if (kind == RT_CYLINDER) {
+                cylinder_hits(r, cld(streamd, i * 8 + 14), cld(streamd, i * 8 + 15), (w0 >> 9) & 1u, h);
+                f += F_CYL;
+            } else {
+                cone_hits(r, cld(streamd, i * 8 + 14), cld(streamd, i * 8 + 15), (w0 >> 9) & 1u, h);
+                f += F_CONE;
+            }
+        }
+        if (act && count) flops += f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bool on = act && k < h.n;
+            if constexpr (HAS_CSG) {
+                if (on && cs_top > 0) {
+                    if (clen < CSG_CAP) { ct[clen] = h.t[k]; cl[clen] = i; clen++; } else err |= 2u;
+                    on = false;
+                }
+            }
+            emit(on, h.t[k], i);
+        }
+        i += 2;
     }
 }
 
 // ---------------------------------------------------------------- patterns
 // Pattern::sub_pattern_at and the kinds (pattern/mod.rs:83-94, pattern/stripe.rs:11-17,
-// ring.rs:12-18, checker.rs:12-18, gradient.rs:12-19, radial_gradient.rs:12-20, blend.rs:11-13).
+// ring.rs:12-18, checker.rs:12-18, gradient.rs:12-19, radial_gradient.rs:12-20, blend.rs:11-13),
+// evaluated with an explicit stack instead of recursion.  A frame is a two-child node
+// (gradient, radial gradient, blend) waiting for its children; choosing kinds (stripe, ring,
+// checker) just descend.  Trees deeper than PAT_DEPTH are rejected by rt_scene_create.
 struct PatTables { const uint32_t* pat_meta; const double* pat_inv; const double* pat_col; };
-template <int DEPTH>
-__device__ __noinline__ V3 sub_pattern_at(PatTables S, uint32_t node, V3 point) {
-    V3 pp = mul_point_v(S.pat_inv + (size_t)node * 12, point);
-    uint32_t kind = S.pat_meta[node * 4 + 0];
-    if (kind == RT_PAT_SOLID) return mk(S.pat_col[node * 4 + 0], S.pat_col[node * 4 + 1], S.pat_col[node * 4 + 2]);
-    uint32_t a = S.pat_meta[node * 4 + 1], b = S.pat_meta[node * 4 + 2];
-    if constexpr (DEPTH <= 0) {
-        return mk(0.0, 0.0, 0.0);  // deeper trees are rejected on the host
-    } else {
-        switch (kind) {
-            case RT_PAT_STRIPE:
-                return sub_pattern_at<DEPTH - 1>(S, fmod(floor(pp.x), 2.0) == 0.0 ? a : b, pp);
-            case RT_PAT_RING:
-                return sub_pattern_at<DEPTH - 1>(S, fmod(floor(hypot(pp.x, pp.z)), 2.0) == 0.0 ? a : b, pp);
-            case RT_PAT_CHECKER:
-                return sub_pattern_at<DEPTH - 1>(S, fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0) == 0.0 ? a : b, pp);
-            case RT_PAT_GRADIENT: {
-                V3 ca = sub_pattern_at<DEPTH - 1>(S, a, pp);
-                V3 distance = sub_pattern_at<DEPTH - 1>(S, b, pp) - ca;
-                double fraction = pp.x - floor(pp.x);
-                return ca + distance * fraction;
+DEV V3 pattern_eval(PatTables S, uint32_t root, V3 object_point) {
+    uint32_t f_node[PAT_DEPTH + 1];
+    uint32_t f_stage[PAT_DEPTH + 1];      // 0: waiting for child a, 1: waiting for child b
+    V3 f_pp[PAT_DEPTH + 1], f_ca[PAT_DEPTH + 1];
+    int top = 0;
+    uint32_t node = root;
+    V3 point = object_point;
+    V3 value = mk(0.0, 0.0, 0.0);
+    for (;;) {
+        // descend until a solid colour is reached
+        for (;;) {
+            V3 pp = mul_point_v(S.pat_inv + (size_t)node * 12, point);
+            uint32_t kind = S.pat_meta[node * 4 + 0];
+            uint32_t a = S.pat_meta[node * 4 + 1], b = S.pat_meta[node * 4 + 2];
+            if (kind == RT_PAT_SOLID) {
+                value = mk(S.pat_col[node * 4 + 0], S.pat_col[node * 4 + 1], S.pat_col[node * 4 + 2]);
+                break;
             }
-            case RT_PAT_RADIAL_GRADIENT: {
-                V3 ca = sub_pattern_at<DEPTH - 1>(S, a, pp);
-                V3 distance = sub_pattern_at<DEPTH - 1>(S, b, pp) - ca;
+            if (kind == RT_PAT_STRIPE) node = fmod(floor(pp.x), 2.0) == 0.0 ? a : b;
+            else if (kind == RT_PAT_RING) node = fmod(floor(hypot(pp.x, pp.z)), 2.0) == 0.0 ? a : b;
+            else if (kind == RT_PAT_CHECKER) node = fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0) == 0.0 ? a : b;
+            else {
+                if (top > PAT_DEPTH) return mk(0.0, 0.0, 0.0);
+                f_node[top] = node; f_stage[top] = 0; f_pp[top] = pp; top++;
+                node = a;
+            }
+            point = pp;
+        }
+        // hand the value to the waiting frames
+        for (;;) {
+            if (top == 0) return value;
+            int t = top - 1;
+            uint32_t n = f_node[t];
+            if (f_stage[t] == 0) {  // child a done: evaluate child b at the same pattern-space point
+                f_ca[t] = value;
+                f_stage[t] = 1;
+                node = S.pat_meta[n * 4 + 2];
+                point = f_pp[t];
+                break;
+            }
+            uint32_t kind = S.pat_meta[n * 4 + 0];
+            V3 ca = f_ca[t], cb = value, pp = f_pp[t];
+            if (kind == RT_PAT_GRADIENT) {
+                V3 distance = cb - ca;
+                double fraction = pp.x - floor(pp.x);
+                value = ca + distance * fraction;
+            } else if (kind == RT_PAT_RADIAL_GRADIENT) {
+                V3 distance = cb - ca;
                 double rd = hypot(pp.x, pp.z);
                 double fraction = rd - floor(rd);
-                return ca + distance * fraction;
+                value = ca + distance * fraction;
+            } else {  // RT_PAT_BLEND
+                value = (ca + cb) / 2.0;
             }
-            default:  // RT_PAT_BLEND
-                return (sub_pattern_at<DEPTH - 1>(S, a, pp) + sub_pattern_at<DEPTH - 1>(S, b, pp)) / 2.0;
+            top--;
         }
     }
 }
@@ -496,13 +573,26 @@ struct NodeRec {  // 64 B: one per traced ray
     double reflective, transparency;
     double reflectance;          // schlick value, or < 0 when the plain sum applies
     uint32_t child_refl, child_refr;  // record indices or NONE
-    uint32_t pad[2];
+    uint32_t hit;                // 1 when the ray hit something (a shade point)
+    uint32_t order;              // deferred shading: subtree size, then position in the row's rng order
+};
+struct TaskRec {  // 80 B: shading input for one shade point, parallel to NodeRec
+    double px, py, pz;   // over_point
+    double nx, ny, nz;   // normal
+    double dx, dy, dz;   // ray direction (eye = -direction)
+    uint32_t pos;        // unit position of the hit leaf
+    uint32_t pad;
 };
 
-struct Counters {  // device-side statistics
-    unsigned long long secondary, shadow, shade, flop;
+struct Counters {  // per-level control words, read back by the host after every k_trace launch
     uint32_t next_count;  // rays appended to the next level
     uint32_t error;       // bit0 queue/record overflow, bit1 list overflow, bit2 NaN distance
+};
+// Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
+// and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
+constexpr uint32_t STAT_SHARDS = 256;
+struct __attribute__((aligned(64))) StatShard {
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, pad[2];
 };
 
 struct LevelArgs {
@@ -516,6 +606,9 @@ struct LevelArgs {
     double half_width, half_height, pixel_size;
     // outputs
     NodeRec* recs;            // records of the whole chunk
+    TaskRec* tasks;           // shading inputs, parallel to recs
+    double* intensity;        // n_lights values per record: Lightable::intensity_at
+    const Rng* rng_states;    // area lights only: one generator state per shade point of the chunk
     uint32_t rec_base;        // first record of this level
     uint32_t next_rec_base;   // first record of the next level
     RayRec* out_rays;
@@ -523,21 +616,32 @@ struct LevelArgs {
     uint32_t rec_cap;         // capacity of recs
     uint32_t depth_remaining; // the reference's `depth` argument at this level
     Counters* counters;
+    StatShard* stats;
 };
 
-struct Comps {  // intersection/computations.rs:12-24
-    V3 point, over_point, under_point, eye, normal, reflectv;
-    double n1, n2;
-    bool inside;
-};
+// ---- per-ray helpers, kept out of line on purpose: each runs once per ray (not once per node),
+// and keeping their registers out of the tree walk's allocation is worth far more than the calls.
 
-// Shape::normal_at (object/shape.rs:60-70) with the per-shape normals
-// (sphere.rs:38-40, plane.rs:26-32, cube.rs:24-40, cylinder.rs:98-108, cone.rs:103-118,
-// triangle.rs:99-104).  `leaf` differs per lane here.
-DEV V3 normal_at(const DevScene& S, uint32_t leaf, V3 world_point, const Ray& world_ray) {
-    const double* m = S.leaf_inv + (size_t)leaf * 12;
-    V3 p = mul_point_v(m, world_point);
-    uint32_t shape = S.leaf_meta[leaf * 4 + 0];
+DEV const double* leaf_inverse(const uint32_t* stream, const double* xform, uint32_t pos) {
+    const uint32_t* rec = stream + (size_t)pos * 16;
+    if ((rec[0] & 0xFFu) == RT_TRIANGLE) return xform + (size_t)rec[4] * 12;
+    return (const double*)rec + 2;
+}
+
+struct HitGeom { V3 point, normal; int inside; };
+
+// point, normal and inside flag of Intersection::prepare_computations (intersection/mod.rs:45-60) with
+// Shape::normal_at (object/shape.rs:60-70) and the per-shape normals (sphere.rs:38-40, plane.rs:26-32,
+// cube.rs:24-40, cylinder.rs:98-108, cone.rs:103-118, triangle.rs:99-104).  `pos` differs per lane.
+__device__ __noinline__ HitGeom hit_geometry(const uint32_t* stream, const double* xform, const double* tri_normals,
+                                             Ray ray, double t, uint32_t pos) {
+    HitGeom g;
+    g.point = ray.o + ray.d * t;
+    const uint32_t* rec = stream + (size_t)pos * 16;
+    const double* recd = (const double*)rec;
+    const double* m = leaf_inverse(stream, xform, pos);
+    V3 p = mul_point_v(m, g.point);
+    uint32_t shape = rec[0] & 0xFFu;
     V3 n;
     if (shape == RT_SPHERE) {
         n = p - mk(0.0, 0.0, 0.0);
@@ -553,7 +657,7 @@ DEV V3 normal_at(const DevScene& S, uint32_t leaf, V3 world_point, const Ray& wo
             n = mk(0.0, 0.0, p.z);
         }
     } else if (shape == RT_CYLINDER || shape == RT_CONE) {
-        double mn = S.leaf_prm[leaf * 4 + 0], mx = S.leaf_prm[leaf * 4 + 1];
+        double mn = recd[14], mx = recd[15];
         double dist = p.x * p.x + p.z * p.z;
         if (dist < 1.0 && p.y >= mx - EPS) n = mk(0.0, 1.0, 0.0);
         else if (dist < 1.0 && p.y <= mn + EPS) n = mk(-0.0, -1.0, -0.0);
@@ -565,47 +669,55 @@ DEV V3 normal_at(const DevScene& S, uint32_t leaf, V3 world_point, const Ray& wo
         }
     } else {
         // Triangle: u, v are recomputed with the same arithmetic that found the hit.
-        const double* td = S.tri + (size_t)S.leaf_meta[leaf * 4 + 1] * 18;
         Ray r;
-        r.o = mul_point_v(m, world_ray.o);
-        r.d = mul_vector_v(m, world_ray.d);
-        double t, u = 0.0, v = 0.0;
-        triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
-        V3 n1 = mk(td[9], td[10], td[11]), n2 = mk(td[12], td[13], td[14]), n3 = mk(td[15], td[16], td[17]);
+        r.o = mul_point_v(m, ray.o);
+        r.d = mul_vector_v(m, ray.d);
+        double tt, u = 0.0, v = 0.0;
+        triangle_hit(r, mk(recd[4], recd[5], recd[6]), mk(recd[7], recd[8], recd[9]), mk(recd[10], recd[11], recd[12]), tt, u, v);
+        const double* nd = tri_normals + (size_t)rec[5] * 9;
+        V3 n1 = mk(nd[0], nd[1], nd[2]), n2 = mk(nd[3], nd[4], nd[5]), n3 = mk(nd[6], nd[7], nd[8]);
         n = n2 * u + n3 * v + n1 * (1.0 - u - v);
     }
     // transpose(inverse) * n, rows 0-2 (object/shape.rs:44-46)
     V3 wn = mk(m[0] * n.x + m[4] * n.y + m[8] * n.z, m[1] * n.x + m[5] * n.y + m[9] * n.z,
                m[2] * n.x + m[6] * n.y + m[10] * n.z);
-    return normalise(wn);
+    g.normal = normalise(wn);
+    V3 eye = -ray.d;
+    if (dot(g.normal, eye) < 0.0) { g.normal = g.normal * -1.0; g.inside = 1; } else g.inside = 0;
+    return g;
 }
+// over_point / under_point (intersection/mod.rs:100-101)
+DEV V3 over_point_of(V3 point, V3 normal) { return point + (normal * 100000.0) * EPS; }
+DEV V3 under_point_of(V3 point, V3 normal) { return point - (normal * 100000.0) * EPS; }
 
-// The container walk of prepare_computations (intersection/mod.rs:62-94) over
-// the collected intersections that sort before the hit, then the hit itself.
-DEV void container_walk(const DevScene& S, double* ts, uint32_t* leafs, int n, double hit_t, uint32_t hit_leaf,
-                        double& n1, double& n2, uint32_t& err) {
+struct N1N2 { double n1, n2; };
+// The container walk of prepare_computations (intersection/mod.rs:62-94) over the collected
+// intersections that sort before the hit, then the hit itself.
+__device__ __noinline__ N1N2 container_walk(const uint32_t* stream, const double* mat, double* ts, uint32_t* poss,
+                                            int n, double hit_t, uint32_t hit_pos) {
     // stable insertion sort by t (arrival order is the index order)
     for (int a = 1; a < n; a++) {
         double ta = ts[a];
-        uint32_t la = leafs[a];
+        uint32_t la = poss[a];
         int b = a - 1;
-        while (b >= 0 && ts[b] > ta) { ts[b + 1] = ts[b]; leafs[b + 1] = leafs[b]; b--; }
-        ts[b + 1] = ta; leafs[b + 1] = la;
+        while (b >= 0 && ts[b] > ta) { ts[b + 1] = ts[b]; poss[b + 1] = poss[b]; b--; }
+        ts[b + 1] = ta; poss[b + 1] = la;
     }
     uint32_t cont[CONT_CAP + 1];
     int cn = 0;
-    uint32_t hit_cls = S.leaf_meta[hit_leaf * 4 + 3] & 0x7FFFFFFFu;
-    n1 = __builtin_nan("");
-    n2 = __builtin_nan("");
+    uint32_t hit_cls = stream[(size_t)hit_pos * 16 + 3];
+    N1N2 r;
+    r.n1 = __builtin_nan("");
+    r.n2 = __builtin_nan("");
     for (int a = 0; a <= n; a++) {
         double t = a < n ? ts[a] : hit_t;
-        uint32_t lf = a < n ? leafs[a] : hit_leaf;
-        uint32_t cls = S.leaf_meta[lf * 4 + 3] & 0x7FFFFFFFu;
+        uint32_t lf = a < n ? poss[a] : hit_pos;
+        uint32_t cls = stream[(size_t)lf * 16 + 3];
         bool is_hit = (a == n) || (cls == hit_cls && approx_eq(t, hit_t));
-        if (is_hit) n1 = cn == 0 ? 1.0 : S.mat[(size_t)S.leaf_meta[cont[cn - 1] * 4 + 2] * 8 + 6];
+        if (is_hit) r.n1 = cn == 0 ? 1.0 : mat[(size_t)stream[(size_t)cont[cn - 1] * 16 + 1] * 8 + 6];
         int k = 0;
         for (; k < cn; k++)
-            if ((S.leaf_meta[cont[k] * 4 + 3] & 0x7FFFFFFFu) == cls) break;
+            if (stream[(size_t)cont[k] * 16 + 3] == cls) break;
         if (k < cn) {
             for (int j = k; j + 1 < cn; j++) cont[j] = cont[j + 1];
             cn--;
@@ -613,112 +725,27 @@ DEV void container_walk(const DevScene& S, double* ts, uint32_t* leafs, int n, d
             cont[cn++] = lf;
         }
         if (is_hit) {
-            n2 = cn == 0 ? 1.0 : S.mat[(size_t)S.leaf_meta[cont[cn - 1] * 4 + 2] * 8 + 6];
+            r.n2 = cn == 0 ? 1.0 : mat[(size_t)stream[(size_t)cont[cn - 1] * 16 + 1] * 8 + 6];
             break;
         }
     }
-    (void)err;
+    return r;
 }
 
 // Computations::schlick (intersection/computations.rs:28-45); powi(5) = x*((x*x)*(x*x)).
-DEV double schlick(const Comps& c) {
-    double cosv = dot(c.eye, c.normal);
-    if (c.n1 > c.n2) {
-        double n_ratio = c.n1 / c.n2;
+DEV double schlick(V3 eye, V3 normal, double n1, double n2) {
+    double cosv = dot(eye, normal);
+    if (n1 > n2) {
+        double n_ratio = n1 / n2;
         double sin2_t = (n_ratio * n_ratio) * (1.0 - cosv * cosv);
         if (sin2_t > 1.0) return 1.0;
         cosv = sqrt(1.0 - sin2_t);
     }
-    double r = (c.n1 - c.n2) / (c.n1 + c.n2);
+    double r = (n1 - n2) / (n1 + n2);
     double r0 = r * r;
     double x = 1.0 - cosv;
     double x2 = x * x;
     return r0 + (1.0 - r0) * (x * (x2 * x2));
-}
-
-// Trace one ray per lane to its closest hit and, for refractive hits, find
-// n1 / n2.  Returns the prepared computations for lanes with a hit.
-template <bool HAS_CSG>
-DEV bool trace_and_prepare(const DevScene& S, const Ray& ray, bool lane_on, double& hit_t, uint32_t& hit_leaf,
-                           Comps& c, uint32_t& n_list, uint32_t& flops, uint32_t& err) {
-    HitSink hs;
-    hs.init();
-    traverse<HAS_CSG>(S, ray, lane_on, hs, flops, true, err);
-    if (hs.nan_seen && hs.arrival >= 2) err |= 4u;
-    bool hit = lane_on && hs.leaf != NONE;
-    hit_t = hs.t;
-    hit_leaf = hs.leaf;
-    n_list = hs.arrival;
-    c.n1 = 1.0; c.n2 = 1.0;
-    uint32_t matb = hit ? S.leaf_meta[hs.leaf * 4 + 2] * 8 : 0;
-    double transparency = hit ? S.mat[matb + 5] : 0.0;
-    bool need = hit && (!approx0(transparency) || transparency > 0.0);
-    if (__ballot(need) != 0ull) {
-        double cts[CONT_CAP];
-        uint32_t cls[CONT_CAP];
-        ContSink cs;
-        cs.hit_t = hs.t; cs.hit_arrival = hs.hit_arrival; cs.arrival = 0; cs.n = 0; cs.overflow = false;
-        cs.ts = cts; cs.leafs = cls;
-        uint32_t dummy = 0;
-        traverse<HAS_CSG>(S, ray, need, cs, dummy, false, err);
-        if (need) {
-            if (cs.overflow) err |= 2u;
-            container_walk(S, cts, cls, cs.n, hs.t, hs.leaf, c.n1, c.n2, err);
-        }
-    }
-    if (hit) {  // intersection/mod.rs:45-109
-        c.point = ray.o + ray.d * hs.t;
-        c.eye = -ray.d;
-        c.normal = normal_at(S, hs.leaf, c.point, ray);
-        if (dot(c.normal, c.eye) < 0.0) { c.normal = c.normal * -1.0; c.inside = true; } else c.inside = false;
-        V3 off = (c.normal * 100000.0) * EPS;
-        c.over_point = c.point + off;
-        c.under_point = c.point - off;
-        c.reflectv = reflect(ray.d, c.normal);
-        flops += F_PREPARE;
-    }
-    return hit;
-}
-
-// World::is_shadowed (world.rs:109-126): closest hit only.
-template <bool HAS_CSG>
-DEV bool is_shadowed(const DevScene& S, V3 light_position, V3 point, bool lane_on, uint32_t& flops, uint32_t& err) {
-    V3 vec = light_position - point;
-    double distance = sqrt(dot(vec, vec));
-    Ray sr;
-    sr.o = point;
-    sr.d = normalise(vec);
-    HitSink hs;
-    hs.init();
-    traverse<HAS_CSG>(S, sr, lane_on, hs, flops, true, err);
-    if (hs.nan_seen && hs.arrival >= 2) err |= 4u;
-    if (lane_on) flops += F_SHADOW;
-    bool shadowed = false;
-    if (lane_on && hs.leaf != NONE) {
-        bool casts = (S.leaf_meta[hs.leaf * 4 + 3] >> 31) != 0;
-        shadowed = casts && hs.t < distance;
-    }
-    return shadowed;
-}
-
-// Material::lighting for one light position list of length 1 (material.rs:47-87,
-// light/point.rs:18-39).  `colour` is pattern_at(...) * light.intensity.
-DEV V3 lighting_point(V3 colour, V3 light_intensity, double ambient_k, double diffuse_k, double specular_k,
-                      double shininess, V3 light_position, V3 point, V3 eye, V3 normal, double intensity) {
-    V3 ambient = colour * ambient_k;
-    V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
-    V3 lv = normalise(light_position - point);
-    double ldn = dot(lv, normal);
-    if (ldn >= 0.0) {
-        diffuse = diffuse + (colour * diffuse_k) * ldn;
-        V3 rv = -reflect(lv, normal);
-        double rde = dot(rv, eye);
-        if (rde > 0.0) {
-            double factor = pow(rde, shininess);
-            specular = specular + (light_intensity * specular_k) * factor;
-        }
-    }
-    return ambient + ((diffuse + specular) / 1.0) * intensity;
 }
 
 // Camera::ray_for_pixel (camera.rs:194-209)
@@ -744,23 +771,28 @@ DEV uint32_t global_row(const LevelArgs& A, uint32_t local_row) {
     return (blk * A.part_world + A.part_rank) * A.part_block + in;
 }
 
-// One recursion level: colour_at for every ray of the level, minus the
-// recursion (world.rs:33-87,129-177).
+// ---------------------------------------------------------------- the three per-ray kernels
+// k_trace  (one launch per recursion level): closest hit, n1/n2, spawn, NodeRec + TaskRec
+// k_shadow (one launch per chunk, all levels at once): Lightable::intensity_at for every light
+// k_light  (one launch per chunk): pattern + Material::lighting; no tree walk, so the
+//          register-hungry pow() stays out of the walking kernels' allocation
+
+// colour_at for every ray of one level, minus the shading and the recursion
+// (world.rs:33-49,129-177; intersection/mod.rs:45-109).
 template <bool PRIMARY, bool HAS_CSG>
-__global__ __launch_bounds__(256) void k_level(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SIMD) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint32_t flops = 0, err = 0;
     bool on;
     uint32_t rec_idx;  // record of this ray (absolute)
     Ray ray;
-    if (PRIMARY) {
-        // 8x8 pixel tile per wave; tiles are dealt to the 8 XCDs in contiguous screen bands
+    if constexpr (PRIMARY) {
+        // 8x8 pixel tile per wave; blocks are dealt to the 8 XCDs in contiguous screen bands
         // (blocks b and b+8 share an XCD and therefore an L2)
         uint32_t nt = A.n_tiles;
         uint32_t nb = gridDim.x, q = nb / 8, r = nb % 8, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
         uint32_t vblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-        uint32_t tile = vblock * 4 + (threadIdx.x >> 6);
+        uint32_t tile = vblock * (TRACE_BLOCK / 64) + (threadIdx.x >> 6);
         bool tile_ok = tile < nt;
         uint32_t tx = tile_ok ? tile % A.tiles_x : 0, ty = tile_ok ? tile / A.tiles_x : 0;
         uint32_t x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
@@ -770,7 +802,7 @@ __global__ __launch_bounds__(256) void k_level(DevScene S, LevelArgs A) {
         ray = ray_for_pixel(A, on ? x : 0, gy);
         if (on) flops += F_PRIMARY;
     } else {
-        uint32_t idx = wave * 64 + lane;
+        uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
         on = idx < A.n_rays;
         rec_idx = A.rec_base + (on ? idx : 0);
         const RayRec* q = A.in_rays + (on ? idx : 0);
@@ -778,116 +810,270 @@ __global__ __launch_bounds__(256) void k_level(DevScene S, LevelArgs A) {
         ray.d = mk(q->dx, q->dy, q->dz);
     }
 
-    double hit_t;
-    uint32_t hit_leaf, n_list;
-    Comps c;
-    bool hit = trace_and_prepare<HAS_CSG>(S, ray, on, hit_t, hit_leaf, c, n_list, flops, err);
-
-    // material of the hit
-    uint32_t matb = hit ? S.leaf_meta[hit_leaf * 4 + 2] * 8 : 0;
-    double m_ambient = S.mat[matb + 0], m_diffuse = S.mat[matb + 1], m_specular = S.mat[matb + 2],
-           m_shininess = S.mat[matb + 3], m_reflective = S.mat[matb + 4], m_transparency = S.mat[matb + 5];
-
-    // shade_hit (world.rs:52-70): lights in order, intensity_at before lighting
-    V3 surface = mk(0.0, 0.0, 0.0);
-    uint32_t n_shadow = 0;
-    if (__ballot(hit) != 0ull) {
-        V3 pat = mk(0.0, 0.0, 0.0);
-        if (hit) {
-            V3 object_point = mul_point_v(S.leaf_inv + (size_t)hit_leaf * 12, c.over_point);
-            uint32_t root = (uint32_t)S.mat[matb + 7];
-            PatTables pt;
-            pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
-            pat = sub_pattern_at<PAT_DEPTH>(pt, root, object_point);
-            flops += F_PATTERN;
-        }
-        for (uint32_t l = 0; l < S.n_lights; l++) {
-            V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
-            V3 lint = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
-            bool shadowed = is_shadowed<HAS_CSG>(S, lpos, c.over_point, hit, flops, err);
-            if (hit) {
-                n_shadow++;
-                double intensity = shadowed ? 0.0 : 1.0;
-                V3 colour = cmul(pat, lint);
-                surface = surface + lighting_point(colour, lint, m_ambient, m_diffuse, m_specular, m_shininess, lpos,
-                                                   c.over_point, c.eye, c.normal, intensity);
-                flops += F_LIGHT;
-            }
+    double cont_t[CONT_CAP];
+    uint32_t cont_pos[CONT_CAP];
+    Walk w;
+    w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
+    w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
+    // job 0: closest hit
+    traverse<HAS_CSG>(S, ray, on, false, w, cont_t, cont_pos, flops, true, err);
+    if (w.nan_seen && w.arrival >= 2) err |= 4u;
+    const bool hit = on && w.pos != NONE;
+    const double hit_t = w.t;
+    const uint32_t hit_pos = w.pos;
+    const double* mat_rec = S.mat + (hit ? (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 : 0);
+    const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
+    // job 1: for refractive hits, the intersections that sort before the hit -> n1, n2
+    double n1 = 1.0, n2 = 1.0;
+    const bool need_cont = hit && (!approx0(m_transparency) || m_transparency > 0.0);
+    if (__ballot(need_cont) != 0ull) {
+        w.hit_t = hit_t; w.want_arrival = w.hit_arrival; w.arrival = 0; w.n = 0; w.overflow = false;
+        uint32_t unused = 0;
+        traverse<HAS_CSG>(S, ray, need_cont, true, w, cont_t, cont_pos, unused, false, err);
+        if (need_cont) {
+            if (w.overflow) err |= 2u;
+            N1N2 nn = container_walk(S.stream, S.mat, cont_t, cont_pos, w.n, hit_t, hit_pos);
+            n1 = nn.n1; n2 = nn.n2;
         }
     }
+    V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
+    if (hit) {
+        HitGeom g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
+        point = g.point; normal = g.normal;
+        flops += F_PREPARE;
+    }
+    const V3 eye = -ray.d;
+    const V3 over = over_point_of(point, normal);
 
     // reflected_colour / refracted_colour spawn tests (world.rs:129-177)
     bool spawn_refl = hit && A.depth_remaining > 0 && m_reflective > 0.0;
     bool spawn_refr = false;
     V3 refr_dir = mk(0.0, 0.0, 0.0);
     if (hit && A.depth_remaining > 0 && !approx0(m_transparency)) {
-        double n_ratio = c.n1 / c.n2;
-        double cos_i = dot(c.eye, c.normal);
+        double n_ratio = n1 / n2;
+        double cos_i = dot(eye, normal);
         double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
         if (!(sin2_t > 1.0)) {
             double cos_t = sqrt(1.0 - sin2_t);
-            refr_dir = c.normal * (n_ratio * cos_i - cos_t) - c.eye * n_ratio;
+            refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
             spawn_refr = true;
         }
         flops += F_REFRACT;
     }
     double reflectance = -1.0;
     if (hit && m_reflective > 0.0 && m_transparency > 0.0) {
-        reflectance = schlick(c);
+        reflectance = schlick(eye, normal, n1, n2);
         flops += F_SCHLICK;
     }
 
-    // append children to the next level: one atomic per wave
+    // append children to the next level: one atomic per block (the counter is a single word,
+    // so per-wave atomics would serialise)
     unsigned long long b_refl = __ballot(spawn_refl), b_refr = __ballot(spawn_refr);
     uint32_t n_refl = __popcll(b_refl), n_refr = __popcll(b_refr);
     uint32_t child_refl = NONE, child_refr = NONE;
+    __shared__ uint32_t s_count[TRACE_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    if (lane == 0) s_count[wave_in_block] = n_refl + n_refr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < TRACE_BLOCK / 64; k++) total += s_count[k];
+        s_base = total ? atomicAdd(&A.counters->next_count, total) : 0u;
+    }
+    __syncthreads();
     if (n_refl + n_refr > 0) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&A.counters->next_count, n_refl + n_refr);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        uint32_t base = s_base;
+        for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[k];
         unsigned long long below = (1ull << lane) - 1ull;
         if (spawn_refl) {
             uint32_t slot = base + __popcll(b_refl & below);
             if (slot < A.out_cap && A.next_rec_base + slot < A.rec_cap) {
+                V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
                 RayRec* o = A.out_rays + slot;
-                o->ox = c.over_point.x; o->oy = c.over_point.y; o->oz = c.over_point.z;
-                o->dx = c.reflectv.x; o->dy = c.reflectv.y; o->dz = c.reflectv.z;
+                o->ox = over.x; o->oy = over.y; o->oz = over.z;
+                o->dx = d_.x; o->dy = d_.y; o->dz = d_.z;
                 child_refl = A.next_rec_base + slot;
             } else err |= 1u;
         }
         if (spawn_refr) {
             uint32_t slot = base + n_refl + __popcll(b_refr & below);
             if (slot < A.out_cap && A.next_rec_base + slot < A.rec_cap) {
+                V3 o_ = under_point_of(point, normal);
                 RayRec* o = A.out_rays + slot;
-                o->ox = c.under_point.x; o->oy = c.under_point.y; o->oz = c.under_point.z;
+                o->ox = o_.x; o->oy = o_.y; o->oz = o_.z;
                 o->dx = refr_dir.x; o->dy = refr_dir.y; o->dz = refr_dir.z;
                 child_refr = A.next_rec_base + slot;
             } else err |= 1u;
         }
     }
-
     if (on) {
         NodeRec* r = A.recs + rec_idx;
-        r->r = surface.x; r->g = surface.y; r->b = surface.z;
-        r->reflective = m_reflective;
-        r->transparency = m_transparency;
+        r->r = 0.0; r->g = 0.0; r->b = 0.0;
+        r->reflective = hit ? m_reflective : 0.0;
+        r->transparency = hit ? m_transparency : 0.0;
         r->reflectance = reflectance;
         r->child_refl = child_refl;
         r->child_refr = child_refr;
+        r->hit = hit ? 1u : 0u;
+        r->order = 0;
+        if (hit) {
+            TaskRec* t = A.tasks + rec_idx;
+            t->px = over.x; t->py = over.y; t->pz = over.z;
+            t->nx = normal.x; t->ny = normal.y; t->nz = normal.z;
+            t->dx = ray.d.x; t->dy = ray.d.y; t->dz = ray.d.z;
+            t->pos = hit_pos;
+        }
     }
 
     // statistics: one atomic per wave and counter
     uint32_t s_shade = wave_sum_u32(hit ? 1u : 0u);
+    uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
+    unsigned long long any_err = __ballot(err != 0);
+    if (lane == 0) {
+        StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
+        if (n_refl + n_refr) atomicAdd(&st->secondary, (unsigned long long)(n_refl + n_refr));
+        if (s_shade) atomicAdd(&st->shade, (unsigned long long)s_shade);
+        atomicAdd(&st->flop_trace, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
+    }
+    if (any_err && err) atomicOr(&A.counters->error, err);
+}
+
+// The area-light rng stream of one shade point (world.rs:60-70): per light, 2*samples draws for
+// intensity_at's positions (light/area.rs:83) and then 2*samples for lighting's (material.rs:64).
+DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++) (void)rng_next(r); }
+
+// Lightable::intensity_at for every shade point and light (light/point.rs:27-38, light/area.rs:75-90):
+// one closest-hit shadow ray per light sample (World::is_shadowed, world.rs:109-126).
+template <bool HAS_CSG>
+__global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S, LevelArgs A) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = idx < A.n_rays;
+    const uint32_t rec_idx = on ? idx : 0;
+    const NodeRec* nr = A.recs + rec_idx;
+    on = on && nr->hit != 0;
+    const TaskRec* q = A.tasks + rec_idx;
+    const V3 over = on ? mk(q->px, q->py, q->pz) : mk(0.0, 0.0, 0.0);
+    Rng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (A.rng_states && on) rng = A.rng_states[nr->order];
+    uint32_t flops = 0, err = 0, n_shadow = 0;
+    if (__ballot(on) != 0ull) {
+        for (uint32_t l = 0; l < S.n_lights; l++) {
+            const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
+            const uint32_t samples = usteps * vsteps;
+            const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
+            const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+            const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
+            const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
+            double unshadowed = 0.0;
+            for (uint32_t k = 0; k < samples; k++) {
+                V3 lp = l0;
+                if (is_area) {  // light/area.rs:48-67: v outer, u inner, r1 before r2
+                    double r1 = rng_unit(rng);
+                    V3 p = l0 + uc * ((double)(k % usteps) + r1);
+                    double r2 = rng_unit(rng);
+                    lp = p + vc * ((double)(k / usteps) + r2);
+                }
+                V3 vec = lp - over;
+                double distance = sqrt(dot(vec, vec));
+                Ray sr;
+                sr.o = over;
+                sr.d = normalise(vec);
+                Walk w;
+                w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
+                w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
+                traverse<HAS_CSG>(S, sr, on, false, w, nullptr, nullptr, flops, true, err);
+                if (w.nan_seen && w.arrival >= 2) err |= 4u;
+                bool shadowed = false;
+                if (on && w.pos != NONE) {
+                    bool casts = (S.stream[(size_t)w.pos * 16] >> 8) & 1u;
+                    shadowed = casts && w.t < distance;
+                }
+                if (!shadowed) unshadowed += 1.0;
+                if (on) { flops += F_SHADOW; n_shadow++; }
+            }
+            if (on) {
+                double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
+                A.intensity[(size_t)rec_idx * S.n_lights + l] = intensity;
+            }
+            if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
+        }
+    }
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
     if (lane == 0) {
-        if (n_refl + n_refr) atomicAdd(&A.counters->secondary, (unsigned long long)(n_refl + n_refr));
-        if (s_shade) atomicAdd(&A.counters->shade, (unsigned long long)s_shade);
-        if (s_shadow) atomicAdd(&A.counters->shadow, (unsigned long long)s_shadow);
-        atomicAdd(&A.counters->flop, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
+        StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
+        if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
+        atomicAdd(&st->flop_shadow, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
     }
     if (any_err && err) atomicOr(&A.counters->error, err);
+}
+
+// The surface colour of every shade point: Σ over lights of Material::lighting (world.rs:58-70,
+// material.rs:47-87) with pattern_at(object, over_point) (pattern/mod.rs:83-87).
+__global__ __launch_bounds__(256) void k_light(DevScene S, LevelArgs A) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t flops = 0;
+    if (idx < A.n_rays && A.recs[idx].hit) {
+    NodeRec* nr = A.recs + idx;
+    const TaskRec* q = A.tasks + idx;
+    const V3 over = mk(q->px, q->py, q->pz), normal = mk(q->nx, q->ny, q->nz);
+    const V3 eye = -mk(q->dx, q->dy, q->dz);
+    const uint32_t hit_pos = q->pos;
+    const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
+    const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
+    V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
+    PatTables pt;
+    pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+    const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
+    Rng rng;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (A.rng_states) rng = A.rng_states[nr->order];
+    V3 surface = mk(0.0, 0.0, 0.0);
+    flops = F_PATTERN;
+    for (uint32_t l = 0; l < S.n_lights; l++) {
+        const uint32_t usteps = S.light_meta[l * 4 + 1], vsteps = S.light_meta[l * 4 + 2];
+        const uint32_t samples = usteps * vsteps;
+        const bool is_area = S.light_meta[l * 4 + 0] == RT_LIGHT_AREA;
+        const double* ld = S.light + (size_t)l * 12;
+        const V3 l0 = mk(ld[0], ld[1], ld[2]), uc = mk(ld[3], ld[4], ld[5]), vc = mk(ld[6], ld[7], ld[8]);
+        const V3 lint = is_area ? mk(ld[9], ld[10], ld[11]) : uc;
+        const double intensity = A.intensity[(size_t)idx * S.n_lights + l];
+        if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
+        V3 colour = cmul(pat, lint);
+        V3 ambient = colour * m_ambient;
+        V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
+        for (uint32_t k = 0; k < samples; k++) {
+            V3 lp = l0;
+            if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
+                double r1 = rng_unit(rng);
+                V3 p = l0 + uc * ((double)(k % usteps) + r1);
+                double r2 = rng_unit(rng);
+                lp = p + vc * ((double)(k / usteps) + r2);
+            }
+            V3 lv = normalise(lp - over);
+            double ldn = dot(lv, normal);
+            if (ldn >= 0.0) {
+                diffuse = diffuse + (colour * m_diffuse) * ldn;
+                V3 rv = -reflect(lv, normal);
+                double rde = dot(rv, eye);
+                if (rde > 0.0) {
+                    double factor = pow(rde, m_shininess);
+                    specular = specular + (lint * m_specular) * factor;
+                }
+            }
+        }
+        surface = surface + (ambient + ((diffuse + specular) / (double)samples) * intensity);
+        flops += F_LIGHT * samples;
+    }
+    nr->r = surface.x; nr->g = surface.y; nr->b = surface.z;
+    }
+    uint32_t s_lo = wave_sum_u32(flops & 0xFFFFu), s_hi = wave_sum_u32(flops >> 16);
+    if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
+        atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
 }
 
 // Colour::to_u8 (colour.rs:63-72): clamp, * 255, round half away from zero, NaN -> 0.
@@ -898,7 +1084,7 @@ DEV uint8_t to_u8(double c) {
 }
 
 // Fold one level of records bottom-up (world.rs:72-86,144,176).  With
-// `emit` set (level 0) the folded colour also goes to the frame buffers.
+// output pointers (level 0) the folded colour also goes to the frame buffers.
 __global__ __launch_bounds__(256) void k_combine(NodeRec* recs, uint32_t base, uint32_t n, double* out_rgb,
                                                  uint8_t* out_rgb8, size_t out_offset) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -922,6 +1108,67 @@ __global__ __launch_bounds__(256) void k_combine(NodeRec* recs, uint32_t base, u
     }
 }
 
+// ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
+// after pixel, and inside a pixel depth-first with the reflected subtree before the refracted one
+// (camera.rs:143-157, world.rs:60-74).
+// (1) bottom-up: order = number of shade points in the subtree
+__global__ __launch_bounds__(256) void k_order_sizes(NodeRec* recs, uint32_t base, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeRec* r = recs + base + i;
+    uint32_t s = 0;
+    if (r->hit) {
+        s = 1;
+        if (r->child_refl != NONE) s += recs[r->child_refl].order;
+        if (r->child_refr != NONE) s += recs[r->child_refr].order;
+    }
+    r->order = s;
+}
+// (2) one lane per row: running offsets of the row's pixels; row_total[row] = shade points in the row
+__global__ __launch_bounds__(64) void k_order_rows(NodeRec* recs, uint32_t width, uint32_t rows, uint32_t* pixel_base,
+                                                   uint32_t* row_total) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    uint32_t acc = 0;
+    for (uint32_t x = 0; x < width; x++) {
+        pixel_base[(size_t)row * width + x] = acc;
+        acc += recs[(size_t)row * width + x].order;
+    }
+    row_total[row] = acc;
+}
+// (3) top-down: order = position of the shade point in the chunk's state array
+__global__ __launch_bounds__(256) void k_order_assign(NodeRec* recs, uint32_t base, uint32_t n, uint32_t width,
+                                                      const uint32_t* pixel_base, const uint32_t* row_base, int level0) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    NodeRec* r = recs + base + i;
+    if (!r->hit) return;
+    uint32_t mine = r->order;  // level 0: still the subtree size; deeper: already the position
+    if (level0) mine = row_base[i / width] + pixel_base[i];
+    uint32_t next = mine + 1;
+    uint32_t cr = r->child_refl, ct = r->child_refr;
+    if (cr != NONE && recs[cr].hit) { uint32_t sz = recs[cr].order; recs[cr].order = next; next += sz; }
+    if (ct != NONE && recs[ct].hit) recs[ct].order = next;
+    r->order = mine;
+}
+// (4) one lane per row: step the row's generator, leaving its state at every shade point
+__global__ __launch_bounds__(64) void k_rng_rows(Rng* states, const uint32_t* row_base, const uint32_t* row_total,
+                                                 const unsigned long long* seeds, uint32_t rows, uint32_t chunk_row0,
+                                                 uint32_t part_block, uint32_t part_rank, uint32_t part_world,
+                                                 uint32_t draws) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    uint32_t local = chunk_row0 + row, gy = local;
+    if (part_world > 1) gy = ((local / part_block) * part_world + part_rank) * part_block + local % part_block;
+    Rng r = rng_seed(seeds[gy]);
+    uint32_t n = row_total[row];
+    Rng* out = states + row_base[row];
+    for (uint32_t k = 0; k < n; k++) {
+        out[k] = r;
+        for (uint32_t d = 0; d < draws; d++) (void)rng_next(r);
+    }
+}
+
 // rt_probe: prepare_computations of the closest hit, for parity checks.
 template <bool HAS_CSG>
 __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const RayRec* rays, double* out, Counters* counters) {
@@ -931,16 +1178,63 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const Ray
     Ray ray;
     ray.o = mk(q->ox, q->oy, q->oz);
     ray.d = mk(q->dx, q->dy, q->dz);
-    double hit_t;
-    uint32_t hit_leaf, n_list, flops = 0, err = 0;
-    Comps c;
-    bool hit = trace_and_prepare<HAS_CSG>(S, ray, on, hit_t, hit_leaf, c, n_list, flops, err);
+    uint32_t flops = 0, err = 0;
+    V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
+    int inside = 0;
+    double n1 = 1.0, n2 = 1.0;
+    double cont_t[CONT_CAP];
+    uint32_t cont_pos[CONT_CAP];
+    Walk w;
+    bool hit = false, need = false;
+    double hit_t = 0.0;
+    uint32_t hit_pos = NONE, n_list = 0;
     double sh[4] = {0.0, 0.0, 0.0, 0.0};
-    for (uint32_t l = 0; l < S.n_lights && l < 4; l++) {
-        V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
-        bool s = is_shadowed<HAS_CSG>(S, lpos, c.over_point, hit, flops, err);
-        double v = s ? 1.0 : 0.0;
-        if (l == 0) sh[0] = v; else if (l == 1) sh[1] = v; else if (l == 2) sh[2] = v; else sh[3] = v;
+    uint32_t n_l = S.n_lights < 4 ? S.n_lights : 4;
+    for (uint32_t job = 0; job < 2 + n_l; job++) {
+        Ray jr = ray;
+        bool jon = on, collect = false;
+        double dist = 0.0;
+        if (job == 1) {
+            if (__ballot(need) == 0ull) continue;
+            jon = need; collect = true;
+            w.hit_t = hit_t; w.want_arrival = w.hit_arrival; w.arrival = 0; w.n = 0; w.overflow = false;
+        } else {
+            if (job >= 2) {
+                uint32_t l = job - 2;
+                V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+                V3 over = over_point_of(point, normal);
+                V3 vec = lpos - over;
+                dist = sqrt(dot(vec, vec));
+                jr.o = over;
+                jr.d = normalise(vec);
+                jon = hit;
+            }
+            w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
+        }
+        traverse<HAS_CSG>(S, jr, jon, collect, w, cont_t, cont_pos, flops, false, err);
+        if (job == 0) {
+            if (w.nan_seen && w.arrival >= 2) err |= 4u;
+            hit = on && w.pos != NONE;
+            hit_t = w.t; hit_pos = w.pos; n_list = w.arrival;
+            if (hit) {
+                HitGeom g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
+                point = g.point; normal = g.normal; inside = g.inside;
+            }
+            double tr = hit ? S.mat[(size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 + 5] : 0.0;
+            need = hit && (!approx0(tr) || tr > 0.0);
+        } else if (job == 1) {
+            if (need) {
+                if (w.overflow) err |= 2u;
+                N1N2 nn = container_walk(S.stream, S.mat, cont_t, cont_pos, w.n, hit_t, hit_pos);
+                n1 = nn.n1; n2 = nn.n2;
+            }
+        } else {
+            bool s = false;
+            if (hit && w.pos != NONE) s = ((S.stream[(size_t)w.pos * 16] >> 8) & 1u) && w.t < dist;
+            double v = s ? 1.0 : 0.0;
+            uint32_t l = job - 2;
+            if (l == 0) sh[0] = v; else if (l == 1) sh[1] = v; else if (l == 2) sh[2] = v; else sh[3] = v;
+        }
     }
     if (on) {
         double* o = out + (size_t)idx * 32;
@@ -948,17 +1242,19 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const Ray
         o[0] = -1.0;
         o[24] = (double)n_list;
         if (hit) {
-            o[0] = (double)hit_leaf; o[1] = hit_t;
-            o[2] = c.point.x; o[3] = c.point.y; o[4] = c.point.z;
-            o[5] = c.over_point.x; o[6] = c.over_point.y; o[7] = c.over_point.z;
-            o[8] = c.under_point.x; o[9] = c.under_point.y; o[10] = c.under_point.z;
-            o[11] = c.eye.x; o[12] = c.eye.y; o[13] = c.eye.z;
-            o[14] = c.normal.x; o[15] = c.normal.y; o[16] = c.normal.z;
-            o[17] = c.inside ? 1.0 : 0.0;
-            o[18] = c.reflectv.x; o[19] = c.reflectv.y; o[20] = c.reflectv.z;
-            // n1 / n2 are only defined by the walk for refractive hits here; opaque hits report them too
-            o[21] = c.n1; o[22] = c.n2;
-            o[23] = schlick(c);
+            V3 over = over_point_of(point, normal), under = under_point_of(point, normal);
+            V3 eye = -ray.d, refl = reflect(ray.d, normal);
+            o[0] = (double)S.stream[(size_t)hit_pos * 16 + 2]; o[1] = hit_t;
+            o[2] = point.x; o[3] = point.y; o[4] = point.z;
+            o[5] = over.x; o[6] = over.y; o[7] = over.z;
+            o[8] = under.x; o[9] = under.y; o[10] = under.z;
+            o[11] = eye.x; o[12] = eye.y; o[13] = eye.z;
+            o[14] = normal.x; o[15] = normal.y; o[16] = normal.z;
+            o[17] = inside ? 1.0 : 0.0;
+            o[18] = refl.x; o[19] = refl.y; o[20] = refl.z;
+            // n1 / n2 come from the container walk for refractive hits; opaque hits report 1.0
+            o[21] = n1; o[22] = n2;
+            o[23] = schlick(eye, normal, n1, n2);
             o[25] = sh[0]; o[26] = sh[1]; o[27] = sh[2]; o[28] = sh[3];
         }
     }
@@ -984,6 +1280,17 @@ int upload(const std::vector<T>& host, T** dev) {
     return RT_OK;
 }
 
+template <class T>
+int grow(T** buf, size_t* cap, size_t want) {
+    if (want <= *cap) return RT_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc((void**)buf, want * sizeof(T)));
+    *cap = want;
+    return RT_OK;
+}
+
 }  // namespace
 
 struct rt_scene {
@@ -998,6 +1305,7 @@ struct rt_scene {
     size_t queue_cap = 0;
     Counters* counters = nullptr;
     Counters* counters_host = nullptr;  // pinned
+    StatShard* stats = nullptr;
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
@@ -1005,6 +1313,20 @@ struct rt_scene {
     std::vector<hipEvent_t> launch_ev;  // start/stop pairs around every level kernel
     size_t chunk_pixels = (size_t)4 << 20;
     size_t recs_per_pixel = 24;
+    // shading inputs
+    TaskRec* tasks = nullptr;
+    size_t task_cap = 0;
+    double* intensity = nullptr;
+    size_t intensity_cap = 0;
+    // rng order (area lights)
+    Rng* rng_states = nullptr;
+    size_t rng_cap = 0;
+    uint32_t* pixel_base = nullptr;
+    size_t pixel_base_cap = 0;
+    uint32_t *row_total = nullptr, *row_base = nullptr;
+    size_t row_cap = 0, row_base_cap = 0;
+    unsigned long long* seeds = nullptr;
+    size_t seeds_cap = 0;
 };
 
 namespace {
@@ -1014,21 +1336,21 @@ int ensure_workspace(rt_scene* s, size_t chunk_px, size_t n_first) {
     size_t want_r = std::max<size_t>(s->recs_per_pixel * std::max(chunk_px, n_first), 4096);
     if (want_r > 0x7FFFFFF0ull) want_r = 0x7FFFFFF0ull;
     if (want_q > s->queue_cap) {
+        size_t cap = 0;
         for (int k = 0; k < 2; k++) {
-            if (s->queue[k]) HIP_TRY(hipFree(s->queue[k]));
-            s->queue[k] = nullptr;
-            HIP_TRY(hipMalloc((void**)&s->queue[k], want_q * sizeof(RayRec)));
+            cap = s->queue_cap;
+            int rc = grow(&s->queue[k], &cap, want_q);
+            if (rc != RT_OK) return rc;
         }
-        s->queue_cap = want_q;
+        s->queue_cap = cap;
     }
-    if (want_r > s->rec_cap) {
-        if (s->recs) HIP_TRY(hipFree(s->recs));
-        s->recs = nullptr;
-        HIP_TRY(hipMalloc((void**)&s->recs, want_r * sizeof(NodeRec)));
-        s->rec_cap = want_r;
-    }
+    int rc = grow(&s->recs, &s->rec_cap, want_r);
+    if (rc != RT_OK) return rc;
+    rc = grow(&s->tasks, &s->task_cap, s->rec_cap);
+    if (rc != RT_OK) return rc;
     if (!s->counters) {
         HIP_TRY(hipMalloc((void**)&s->counters, sizeof(Counters)));
+        HIP_TRY(hipMalloc((void**)&s->stats, STAT_SHARDS * sizeof(StatShard)));
         HIP_TRY(hipHostMalloc((void**)&s->counters_host, sizeof(Counters)));
         for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
     }
@@ -1036,23 +1358,39 @@ int ensure_workspace(rt_scene* s, size_t chunk_px, size_t n_first) {
 }
 
 struct RunTotals {
-    uint64_t secondary = 0, shadow = 0, shade = 0, flop = 0, launches = 0;
+    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0;
+    uint64_t trace_launches = 0;
     uint32_t levels = 0;
-    double ms_trace = 0, ms_combine = 0;
+    double ms_trace = 0, ms_shadow = 0, ms_light = 0, ms_combine = 0;
 };
 
-// Run the levels for one batch of first-level rays (a pixel chunk, or rays
-// already placed in queue[0]) and fold the records.  Returns RT_ERR_CAPACITY
-// with *overflow set when a queue or the record buffer was too small.
+struct FirstLevel {   // where the first level's rays come from
+    bool primary;     // true: pixels of a chunk; false: rays already in queue[0]
+    uint32_t n;       // number of first-level rays
+    uint32_t width, rows;            // primary only
+    const unsigned long long* seeds; // device: per global row (primary) or per ray; area lights only
+};
+
+// Run the levels for one batch of first-level rays, shade every shade point and fold the
+// records.  Returns RT_ERR_CAPACITY with *overflow set when a queue or the record buffer
+// was too small.
 template <bool HAS_CSG>
-int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint32_t depth, double* out_rgb,
+int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
                uint8_t* out_rgb8, size_t out_offset, RunTotals& tot, bool* overflow) {
     *overflow = false;
     std::vector<uint32_t> level_base, level_n;
     HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(Counters), 0));
-    uint32_t n = n_first, rec_base = 0;
+    HIP_TRY(hipMemsetAsync(s->stats, 0, STAT_SHARDS * sizeof(StatShard), 0));
+    uint32_t n = first.n, rec_base = 0;
     int qi = 0;
-    HIP_TRY(hipEventRecord(s->ev[0], 0));
+    auto event = [&](size_t k) -> hipEvent_t {
+        while (s->launch_ev.size() <= k) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            s->launch_ev.push_back(e);
+        }
+        return s->launch_ev[k];
+    };
     for (uint32_t level = 0;; level++) {
         LevelArgs A = base;
         A.n_rays = n;
@@ -1060,31 +1398,26 @@ int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint
         A.out_rays = s->queue[qi ^ 1];
         A.out_cap = (uint32_t)std::min<size_t>(s->queue_cap, 0xFFFFFFF0u);
         A.recs = s->recs;
+        A.tasks = s->tasks;
         A.rec_cap = (uint32_t)s->rec_cap;
         A.rec_base = rec_base;
         A.next_rec_base = rec_base + n;
         A.depth_remaining = depth >= level ? depth - level : 0;
         A.counters = s->counters;
+        A.stats = s->stats;
         if ((size_t)rec_base + n > s->rec_cap) { *overflow = true; return RT_ERR_CAPACITY; }
         level_base.push_back(rec_base);
         level_n.push_back(n);
-        while (s->launch_ev.size() < 2 * ((size_t)level + 1)) {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreate(&e));
-            s->launch_ev.push_back(e);
-        }
-        HIP_TRY(hipEventRecord(s->launch_ev[2 * level], 0));
-        if (primary && level == 0) {
-            uint32_t waves = A.n_tiles;
-            uint32_t blocks = (waves + 3) / 4;
-            hipLaunchKernelGGL((k_level<true, HAS_CSG>), dim3(blocks), dim3(256), 0, 0, s->dev, A);
-        } else {
-            uint32_t blocks = (n + 255) / 256;
-            hipLaunchKernelGGL((k_level<false, HAS_CSG>), dim3(blocks), dim3(256), 0, 0, s->dev, A);
-        }
-        tot.launches++;
+        HIP_TRY(hipEventRecord(event(2 * level), 0));
+        if (first.primary && level == 0)
+            hipLaunchKernelGGL((k_trace<true, HAS_CSG>), dim3((A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)),
+                               dim3(TRACE_BLOCK), 0, 0, s->dev, A);
+        else
+            hipLaunchKernelGGL((k_trace<false, HAS_CSG>), dim3((n + TRACE_BLOCK - 1) / TRACE_BLOCK), dim3(TRACE_BLOCK), 0, 0,
+                               s->dev, A);
+        tot.trace_launches++;
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->launch_ev[2 * level + 1], 0));
+        HIP_TRY(hipEventRecord(event(2 * level + 1), 0));
         HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
         HIP_TRY(hipStreamSynchronize(0));
         uint32_t next = s->counters_host->next_count;
@@ -1102,37 +1435,103 @@ int run_levels(rt_scene* s, LevelArgs base, bool primary, uint32_t n_first, uint
         n = next;
         qi ^= 1;
     }
-    HIP_TRY(hipEventRecord(s->ev[1], 0));
-    // bottom-up fold; level 0 writes the outputs
-    for (int level = (int)level_n.size() - 1; level >= 0; level--) {
-        uint32_t ln = level_n[level];
-        uint32_t blocks = (ln + 255) / 256;
-        bool emit = level == 0;
-        hipLaunchKernelGGL(k_combine, dim3(blocks), dim3(256), 0, 0, s->recs, level_base[level], ln,
-                           emit ? out_rgb : nullptr, emit ? out_rgb8 : nullptr, out_offset);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev[2], 0));
-    HIP_TRY(hipStreamSynchronize(0));
+    const size_t n_levels = level_n.size();
+    const uint32_t total_recs = rec_base;
     float ms = 0;
-    for (size_t level = 0; level < level_n.size(); level++) {
+    for (size_t level = 0; level < n_levels; level++) {
         HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[2 * level], s->launch_ev[2 * level + 1]));
         tot.ms_trace += ms;
     }
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev[1], s->ev[2]));
+
+    if (s->has_area) {
+        // number the shade points in the reference's rng order and step the row generators to them
+        const uint32_t n0 = level_n[0];
+        const uint32_t width = first.primary ? first.width : 1, rows = first.primary ? first.rows : n0;
+        for (int level = (int)n_levels - 1; level >= 0; level--)
+            hipLaunchKernelGGL(k_order_sizes, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->recs,
+                               level_base[level], level_n[level]);
+        int rc = grow(&s->pixel_base, &s->pixel_base_cap, (size_t)n0);
+        if (rc == RT_OK) rc = grow(&s->row_total, &s->row_cap, (size_t)rows);
+        if (rc == RT_OK) rc = grow(&s->row_base, &s->row_base_cap, (size_t)rows);
+        if (rc != RT_OK) return rc;
+        hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->recs, width, rows, s->pixel_base,
+                           s->row_total);
+        std::vector<uint32_t> totals(rows), bases(rows);
+        HIP_TRY(hipMemcpy(totals.data(), s->row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint64_t acc = 0;
+        for (uint32_t r = 0; r < rows; r++) { bases[r] = (uint32_t)acc; acc += totals[r]; }
+        if (acc > 0xFFFFFFF0ull) return fail(RT_ERR_CAPACITY, "too many shade points in one chunk");
+        HIP_TRY(hipMemcpy(s->row_base, bases.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice));
+        rc = grow(&s->rng_states, &s->rng_cap, std::max<size_t>((size_t)acc, 1));
+        if (rc != RT_OK) return rc;
+        for (size_t level = 0; level < n_levels; level++)
+            hipLaunchKernelGGL(k_order_assign, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->recs,
+                               level_base[level], level_n[level], width, s->pixel_base, s->row_base, level == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k_rng_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->rng_states, s->row_base, s->row_total,
+                           first.seeds, rows, first.primary ? base.chunk_row0 : 0u, first.primary ? base.part_block : 0u,
+                           first.primary ? base.part_rank : 0u, first.primary ? base.part_world : 1u,
+                           s->dev.draws_per_shade);
+        HIP_TRY(hipGetLastError());
+    }
+
+    // shade every shade point of the chunk: shadow rays, then lighting
+    {
+        int rc = grow(&s->intensity, &s->intensity_cap, (size_t)total_recs * s->dev.n_lights);
+        if (rc != RT_OK) return rc;
+        LevelArgs A = base;
+        A.n_rays = total_recs;
+        A.recs = s->recs;
+        A.tasks = s->tasks;
+        A.intensity = s->intensity;
+        A.rng_states = s->has_area ? s->rng_states : nullptr;
+        A.counters = s->counters;
+        A.stats = s->stats;
+        const size_t e = 2 * n_levels;
+        HIP_TRY(hipEventRecord(event(e), 0));
+        hipLaunchKernelGGL((k_shadow<HAS_CSG>), dim3((total_recs + 255) / 256), dim3(256), 0, 0, s->dev, A);
+        HIP_TRY(hipEventRecord(event(e + 1), 0));
+        hipLaunchKernelGGL(k_light, dim3((total_recs + 255) / 256), dim3(256), 0, 0, s->dev, A);
+        HIP_TRY(hipEventRecord(event(e + 2), 0));
+        HIP_TRY(hipGetLastError());
+    }
+
+    // bottom-up fold; level 0 writes the outputs
+    for (int level = (int)n_levels - 1; level >= 0; level--) {
+        uint32_t ln = level_n[level];
+        bool emit = level == 0;
+        hipLaunchKernelGGL(k_combine, dim3((ln + 255) / 256), dim3(256), 0, 0, s->recs, level_base[level], ln,
+                           emit ? out_rgb : nullptr, emit ? out_rgb8 : nullptr, out_offset);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(event(2 * n_levels + 3), 0));
+    HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
+    std::vector<StatShard> shards(STAT_SHARDS);
+    HIP_TRY(hipMemcpyAsync(shards.data(), s->stats, STAT_SHARDS * sizeof(StatShard), hipMemcpyDeviceToHost, 0));
+    HIP_TRY(hipStreamSynchronize(0));
+    {
+        uint32_t error = s->counters_host->error;
+        if (error & 2u) return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed");
+        if (error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
+    }
+    const size_t e = 2 * n_levels;
+    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e], s->launch_ev[e + 1]));
+    tot.ms_shadow += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 1], s->launch_ev[e + 2]));
+    tot.ms_light += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 2], s->launch_ev[e + 3]));
     tot.ms_combine += ms;
-    tot.secondary += s->counters_host->secondary;
-    tot.shadow += s->counters_host->shadow;
-    tot.shade += s->counters_host->shade;
-    tot.flop += s->counters_host->flop;
-    tot.levels = std::max<uint32_t>(tot.levels, (uint32_t)level_n.size());
+    for (const StatShard& sh : shards) {
+        tot.secondary += sh.secondary; tot.shadow += sh.shadow; tot.shade += sh.shade;
+        tot.flop_trace += sh.flop_trace; tot.flop_shadow += sh.flop_shadow; tot.flop_light += sh.flop_light;
+    }
+    tot.levels = std::max<uint32_t>(tot.levels, (uint32_t)n_levels);
     return RT_OK;
 }
 
-int run_levels_dispatch(rt_scene* s, const LevelArgs& base, bool primary, uint32_t n_first, uint32_t depth,
+int run_levels_dispatch(rt_scene* s, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
                         double* out_rgb, uint8_t* out_rgb8, size_t out_offset, RunTotals& tot, bool* overflow) {
-    if (s->has_csg) return run_levels<true>(s, base, primary, n_first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
-    return run_levels<false>(s, base, primary, n_first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
+    if (s->has_csg) return run_levels<true>(s, base, first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
+    return run_levels<false>(s, base, first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
 }
 
 uint32_t local_rows(const rt_camera* cam, const rt_partition* p) {
@@ -1141,6 +1540,26 @@ uint32_t local_rows(const rt_camera* cam, const rt_partition* p) {
     for (uint32_t b = 0; b * p->block_rows < cam->height; b++)
         if (b % p->world == p->rank) rows += std::min(p->block_rows, cam->height - b * p->block_rows);
     return rows;
+}
+
+int upload_seeds(rt_scene* s, const uint64_t* seeds, size_t n) {
+    int rc = grow(&s->seeds, &s->seeds_cap, std::max<size_t>(n, 1));
+    if (rc != RT_OK) return rc;
+    std::vector<unsigned long long> tmp(n, 0);
+    if (seeds) for (size_t i = 0; i < n; i++) tmp[i] = seeds[i];
+    HIP_TRY(hipMemcpy(s->seeds, tmp.data(), n * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+int upload_rays(rt_scene* s, uint32_t n, const double* rays) {
+    std::vector<RayRec> host(n);
+    for (uint32_t i = 0; i < n; i++) {
+        std::memset(&host[i], 0, sizeof(RayRec));
+        host[i].ox = rays[6 * (size_t)i + 0]; host[i].oy = rays[6 * (size_t)i + 1]; host[i].oz = rays[6 * (size_t)i + 2];
+        host[i].dx = rays[6 * (size_t)i + 3]; host[i].dy = rays[6 * (size_t)i + 4]; host[i].dz = rays[6 * (size_t)i + 5];
+    }
+    HIP_TRY(hipMemcpy(s->queue[0], host.data(), (size_t)n * sizeof(RayRec), hipMemcpyHostToDevice));
+    return RT_OK;
 }
 
 }  // namespace
@@ -1199,39 +1618,88 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     }
     for (uint32_t i = 0; i < d->n_materials; i++)
         if (d->material_pattern[i] >= d->n_patterns) return fail(RT_ERR_INVALID, "pattern index out of range");
+    uint64_t draws = 0;
+    bool has_area = false;
+    for (uint32_t i = 0; i < d->n_lights; i++) {
+        if (d->light_kind[i] == RT_LIGHT_AREA) {
+            has_area = true;
+            uint64_t samples = (uint64_t)d->light_steps[(size_t)i * 2] * d->light_steps[(size_t)i * 2 + 1];
+            if (samples == 0 || samples > (1u << 20)) return fail(RT_ERR_INVALID, "area light step counts out of range");
+            draws += 4 * samples;  // positions() twice per shade point, two draws per sample (area.rs:57-67,83; material.rs:64)
+        } else if (d->light_kind[i] != RT_LIGHT_POINT) {
+            return fail(RT_ERR_INVALID, "unknown light kind");
+        }
+    }
+
+    // ---- node stream
+    std::vector<uint32_t> unit_of(d->n_nodes + 1);
+    uint32_t units = 0;
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        unit_of[i] = units;
+        units += d->node_kind[i] == RT_NODE_LEAF ? 2 : 1;
+    }
+    unit_of[d->n_nodes] = units;
+    std::vector<uint32_t> stream((size_t)(units + 4) * 16, 0);  // padded: the walk may read one record ahead
+    std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0);
+    std::map<std::vector<uint64_t>, uint32_t> xform_ids;
+    bool has_csg = false;
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        uint32_t* rec = &stream[(size_t)unit_of[i] * 16];
+        double* recd = (double*)rec;
+        if (d->node_kind[i] == RT_NODE_LEAF) {
+            uint32_t leaf = d->node_arg[i];
+            uint32_t shape = d->leaf_shape[leaf];
+            bool closed = d->leaf_param[(size_t)leaf * 3 + 2] != 0.0;
+            rec[0] = shape | (d->leaf_casts_shadow[leaf] ? 1u << 8 : 0u) | (closed ? 1u << 9 : 0u);
+            rec[1] = d->leaf_material[leaf];
+            rec[2] = leaf;
+            rec[3] = d->leaf_class[leaf];
+            const double* inv = d->leaf_inv + (size_t)leaf * 12;
+            if (shape == RT_TRIANGLE) {
+                std::vector<uint64_t> key(12);
+                std::memcpy(key.data(), inv, 96);
+                auto it = xform_ids.find(key);
+                uint32_t id;
+                if (it == xform_ids.end()) {
+                    id = (uint32_t)xform_ids.size();
+                    xform_ids.emplace(key, id);
+                    xforms.insert(xforms.end(), inv, inv + 12);
+                } else id = it->second;
+                uint32_t tri = d->leaf_tri[leaf];
+                rec[4] = id;
+                rec[5] = tri;
+                for (int k = 0; k < 9; k++) recd[4 + k] = d->tri_data[(size_t)tri * 18 + k];
+                for (int k = 0; k < 9; k++) tri_normals[(size_t)tri * 9 + k] = d->tri_data[(size_t)tri * 18 + 9 + k];
+            } else {
+                for (int k = 0; k < 12; k++) recd[2 + k] = inv[k];
+                recd[14] = d->leaf_param[(size_t)leaf * 3 + 0];
+                recd[15] = d->leaf_param[(size_t)leaf * 3 + 1];
+            }
+        } else {
+            bool csg = d->node_kind[i] == RT_NODE_CSG;
+            has_csg |= csg;
+            rec[0] = csg ? K_CSG : K_GROUP;
+            rec[1] = unit_of[d->node_skip[i]];
+            rec[2] = csg ? d->node_arg[i] : 0;
+            for (int k = 0; k < 6; k++) recd[2 + k] = d->node_bbox[(size_t)i * 6 + k];
+        }
+    }
 
     auto* s = new rt_scene();
-    hipGetDevice(&s->device);
+    (void)hipGetDevice(&s->device);
+    s->has_csg = has_csg;
+    s->has_area = has_area;
     auto keep = [&](void* p) { s->allocations.push_back(p); };
     int rc = RT_OK;
-#define UP(vec, field)                                   \
-    do {                                                 \
-        decltype(vec)::value_type* p_ = nullptr;         \
-        rc = upload(vec, &p_);                           \
+#define UP(vec, field)                                       \
+    do {                                                     \
+        decltype(vec)::value_type* p_ = nullptr;             \
+        rc = upload(vec, &p_);                               \
         if (rc != RT_OK) { rt_scene_destroy(s); return rc; } \
-        keep(p_);                                        \
-        s->dev.field = p_;                               \
+        keep(p_);                                            \
+        s->dev.field = p_;                                   \
     } while (0)
 
-    std::vector<uint32_t> node_meta(d->n_nodes * 4, 0);
-    for (uint32_t i = 0; i < d->n_nodes; i++) {
-        node_meta[i * 4 + 0] = d->node_kind[i];
-        node_meta[i * 4 + 1] = d->node_skip[i];
-        node_meta[i * 4 + 2] = d->node_arg[i];
-        if (d->node_kind[i] == RT_NODE_CSG) s->has_csg = true;
-    }
-    std::vector<double> node_bbox(d->node_bbox, d->node_bbox + (size_t)d->n_nodes * 6);
-    std::vector<double> leaf_inv(d->leaf_inv, d->leaf_inv + (size_t)d->n_leaves * 12);
-    std::vector<double> leaf_prm((size_t)d->n_leaves * 4, 0.0);
-    std::vector<uint32_t> leaf_meta((size_t)d->n_leaves * 4, 0);
-    for (uint32_t i = 0; i < d->n_leaves; i++) {
-        for (int k = 0; k < 3; k++) leaf_prm[(size_t)i * 4 + k] = d->leaf_param[(size_t)i * 3 + k];
-        leaf_meta[(size_t)i * 4 + 0] = d->leaf_shape[i];
-        leaf_meta[(size_t)i * 4 + 1] = d->leaf_tri[i];
-        leaf_meta[(size_t)i * 4 + 2] = d->leaf_material[i];
-        leaf_meta[(size_t)i * 4 + 3] = (d->leaf_class[i] & 0x7FFFFFFFu) | (d->leaf_casts_shadow[i] ? 0x80000000u : 0u);
-    }
-    std::vector<double> tri(d->tri_data, d->tri_data + (size_t)d->n_tris * 18);
     std::vector<uint32_t> csg_op(d->csg_op, d->csg_op + d->n_csgs);
     size_t words = ((size_t)d->n_classes + 63) / 64;
     std::vector<uint64_t> csg_bits(d->csg_left_bits, d->csg_left_bits + (size_t)d->n_csgs * words);
@@ -1252,17 +1720,17 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<double> light(d->light_data, d->light_data + (size_t)d->n_lights * 12);
     std::vector<uint32_t> light_meta((size_t)d->n_lights * 4, 0);
     for (uint32_t i = 0; i < d->n_lights; i++) {
+        bool area = d->light_kind[i] == RT_LIGHT_AREA;
         light_meta[(size_t)i * 4 + 0] = d->light_kind[i];
-        light_meta[(size_t)i * 4 + 1] = d->light_steps[(size_t)i * 2];
-        light_meta[(size_t)i * 4 + 2] = d->light_steps[(size_t)i * 2 + 1];
-        if (d->light_kind[i] == RT_LIGHT_AREA) s->has_area = true;
-        else if (d->light_kind[i] != RT_LIGHT_POINT) { rt_scene_destroy(s); return fail(RT_ERR_INVALID, "unknown light kind"); }
+        light_meta[(size_t)i * 4 + 1] = area ? d->light_steps[(size_t)i * 2] : 1;
+        light_meta[(size_t)i * 4 + 2] = area ? d->light_steps[(size_t)i * 2 + 1] : 1;
     }
-    s->dev.n_nodes = d->n_nodes; s->dev.n_leaves = d->n_leaves; s->dev.n_lights = d->n_lights;
+    s->dev.n_units = units; s->dev.n_lights = d->n_lights;
     s->dev.class_words = (uint32_t)words;
-    UP(node_meta, node_meta); UP(node_bbox, node_bbox); UP(leaf_inv, leaf_inv); UP(leaf_prm, leaf_prm);
-    UP(leaf_meta, leaf_meta); UP(tri, tri); UP(csg_op, csg_op); UP(csg_bits, csg_bits); UP(mat, mat);
-    UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light); UP(light_meta, light_meta);
+    s->dev.draws_per_shade = (uint32_t)draws;
+    UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
+    UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);
+    UP(light_meta, light_meta);
 #undef UP
     *out = s;
     return RT_OK;
@@ -1274,9 +1742,17 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->recs) (void)hipFree(s->recs);
     for (auto& q : s->queue) if (q) (void)hipFree(q);
     if (s->counters) (void)hipFree(s->counters);
+    if (s->stats) (void)hipFree(s->stats);
     if (s->counters_host) (void)hipHostFree(s->counters_host);
     if (s->stage_rgb) (void)hipFree(s->stage_rgb);
     if (s->stage_rgb8) (void)hipFree(s->stage_rgb8);
+    if (s->tasks) (void)hipFree(s->tasks);
+    if (s->intensity) (void)hipFree(s->intensity);
+    if (s->rng_states) (void)hipFree(s->rng_states);
+    if (s->pixel_base) (void)hipFree(s->pixel_base);
+    if (s->row_total) (void)hipFree(s->row_total);
+    if (s->row_base) (void)hipFree(s->row_base);
+    if (s->seeds) (void)hipFree(s->seeds);
     for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : s->launch_ev) if (e) (void)hipEventDestroy(e);
     delete s;
@@ -1290,9 +1766,12 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     if (p.world == 0) p.world = 1;
     if (p.world > 1 && (p.block_rows == 0 || p.block_rows % 8 != 0 || p.rank >= p.world))
         return fail(RT_ERR_INVALID, "partition needs block_rows a multiple of 8 and rank < world");
-    if (s->has_area) return fail(RT_ERR_UNSUPPORTED, "area lights are not available on the device path yet");
-    (void)row_seeds;
+    if (s->has_area && !row_seeds) return fail(RT_ERR_INVALID, "a scene with an area light needs the per-row seeds");
     HIP_TRY(hipSetDevice(s->device));
+    if (s->has_area) {
+        int rc = upload_seeds(s, row_seeds, cam->height);
+        if (rc != RT_OK) return rc;
+    }
 
     const uint32_t W = cam->width;
     const uint32_t rows = local_rows(cam, &p);
@@ -1312,6 +1791,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
             if (s->stage_rgb) HIP_TRY(hipFree(s->stage_rgb));
             if (s->stage_rgb8) HIP_TRY(hipFree(s->stage_rgb8));
             s->stage_rgb = nullptr; s->stage_rgb8 = nullptr;
+            s->stage_pixels = 0;
             HIP_TRY(hipMalloc((void**)&s->stage_rgb, total_px * 3 * sizeof(double)));
             HIP_TRY(hipMalloc((void**)&s->stage_rgb8, total_px * 3));
             s->stage_pixels = total_px;
@@ -1338,8 +1818,9 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         A.part_block = p.block_rows; A.part_rank = p.rank; A.part_world = p.world;
         std::memcpy(A.cam_inv, cam->inv, sizeof A.cam_inv);
         A.half_width = cam->half_width; A.half_height = cam->half_height; A.pixel_size = cam->pixel_size;
+        FirstLevel first{true, (uint32_t)px, W, nr, s->seeds};
         bool overflow = false;
-        rc = run_levels_dispatch(s, A, true, (uint32_t)px, depth, d_rgb, d_rgb8, (size_t)r0 * W, tot, &overflow);
+        rc = run_levels_dispatch(s, A, first, depth, d_rgb, d_rgb8, (size_t)r0 * W, tot, &overflow);
         if (rc == RT_ERR_CAPACITY && overflow) {
             if (nr <= 8) {
                 // cannot split further: grow the per-pixel record budget instead
@@ -1376,9 +1857,13 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->chunks = chunks;
         stats->ms_total = ms;
         stats->ms_trace = tot.ms_trace;
+        stats->ms_shadow = tot.ms_shadow;
+        stats->ms_light = tot.ms_light;
         stats->ms_combine = tot.ms_combine;
-        stats->trace_launches = tot.launches;
-        stats->algorithmic_flop = tot.flop;
+        stats->trace_launches = tot.trace_launches;
+        stats->flop_trace = tot.flop_trace;
+        stats->flop_shadow = tot.flop_shadow;
+        stats->flop_light = tot.flop_light;
     }
     return RT_OK;
 }
@@ -1386,30 +1871,29 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
 int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, const uint64_t* seeds, double* out_rgb) {
     if (!s || (n && (!rays || !out_rgb))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;
-    if (s->has_area) return fail(RT_ERR_UNSUPPORTED, "area lights are not available on the device path yet");
-    (void)seeds;
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_workspace(s, 0, n);
     if (rc != RT_OK) return rc;
-    std::vector<RayRec> host(n);
-    for (uint32_t i = 0; i < n; i++) {
-        std::memset(&host[i], 0, sizeof(RayRec));
-        host[i].ox = rays[6 * (size_t)i + 0]; host[i].oy = rays[6 * (size_t)i + 1]; host[i].oz = rays[6 * (size_t)i + 2];
-        host[i].dx = rays[6 * (size_t)i + 3]; host[i].dy = rays[6 * (size_t)i + 4]; host[i].dz = rays[6 * (size_t)i + 5];
+    if (s->has_area) {
+        rc = upload_seeds(s, seeds, n);  // a missing list seeds every ray's generator with 0
+        if (rc != RT_OK) return rc;
     }
-    HIP_TRY(hipMemcpy(s->queue[0], host.data(), (size_t)n * sizeof(RayRec), hipMemcpyHostToDevice));
+    rc = upload_rays(s, n, rays);
+    if (rc != RT_OK) return rc;
     double* d_out = nullptr;
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(double)));
     LevelArgs A{};
+    A.part_world = 1;
     RunTotals tot;
     bool overflow = false;
     for (;;) {
-        rc = run_levels_dispatch(s, A, false, n, depth, d_out, nullptr, 0, tot, &overflow);
+        FirstLevel first{false, n, 1, n, s->seeds};
+        rc = run_levels_dispatch(s, A, first, depth, d_out, nullptr, 0, tot, &overflow);
         if (rc == RT_ERR_CAPACITY && overflow && s->recs_per_pixel < 4096) {
             s->recs_per_pixel *= 4;
             int rc2 = ensure_workspace(s, 0, n);
+            if (rc2 == RT_OK) rc2 = upload_rays(s, n, rays);
             if (rc2 != RT_OK) { (void)hipFree(d_out); return rc2; }
-            HIP_TRY(hipMemcpy(s->queue[0], host.data(), (size_t)n * sizeof(RayRec), hipMemcpyHostToDevice));
             continue;
         }
         break;
@@ -1430,13 +1914,8 @@ int rt_probe(rt_scene* s, uint32_t n, const double* rays, double* out) {
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure_workspace(s, 0, n);
     if (rc != RT_OK) return rc;
-    std::vector<RayRec> host(n);
-    for (uint32_t i = 0; i < n; i++) {
-        std::memset(&host[i], 0, sizeof(RayRec));
-        host[i].ox = rays[6 * (size_t)i + 0]; host[i].oy = rays[6 * (size_t)i + 1]; host[i].oz = rays[6 * (size_t)i + 2];
-        host[i].dx = rays[6 * (size_t)i + 3]; host[i].dy = rays[6 * (size_t)i + 4]; host[i].dz = rays[6 * (size_t)i + 5];
-    }
-    HIP_TRY(hipMemcpy(s->queue[0], host.data(), (size_t)n * sizeof(RayRec), hipMemcpyHostToDevice));
+    rc = upload_rays(s, n, rays);
+    if (rc != RT_OK) return rc;
     double* d_out = nullptr;
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 32 * sizeof(double)));
     HIP_TRY(hipMemset(s->counters, 0, sizeof(Counters)));
