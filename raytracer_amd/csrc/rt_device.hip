@@ -55,6 +55,9 @@ constexpr int WAVE = 64;
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256   // threads per k_trace block: one queue-append atomic per block
 #endif
+#ifndef REC_CAP
+#define REC_CAP 8         // candidates per lane recorded in LDS during the closest-hit walk (16 B each)
+#endif
 
 #define DEV __device__ __forceinline__
 #define CADDR __attribute__((address_space(4)))
@@ -111,6 +114,7 @@ struct Ray { V3 o, d; };
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
+    uint32_t flags;             // bit0: some material has a nonzero transparency
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
     const double* tri_normals;  // n_tris*9
@@ -329,7 +333,11 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
 //  * List::hit (intersection/list.rs:24-32) = first minimum among t > 0, so a
 //    strict `<` against the running best keeps the reference's tie-break;
 //  * the container walk (intersection/mod.rs:62-94) needs every intersection
-//    that sorts before the hit; a second walk (collect = true) gathers them.
+//    that sorts before the hit.  Only an intersection below the running best can
+//    do so (an equal t that arrives later sorts after the hit), so the closest-hit
+//    walk records those (record = true) and the caller drops the ones that the
+//    final hit undercut.  A second walk (collect = true) gathers exactly the
+//    needed ones and is the fallback when the recorded list overflowed.
 struct Walk {
     // closest hit so far
     double t;
@@ -343,12 +351,23 @@ struct Walk {
     bool overflow;
 };
 
+// Where a walk keeps the (t, unit position, class) of intersections for the container walk:
+// entry k of this lane is at index k*stride.  The fast buffer is in LDS (lanes interleaved,
+// stride = block size), the overflow buffer is lane-private scratch (stride 1).
+struct ContBuf {
+    double* t;
+    uint32_t* pos;
+    uint32_t* cls;
+    int stride, cap;
+    DEV void put(int k, double tt, uint32_t p, uint32_t c) const { t[k * stride] = tt; pos[k * stride] = p; cls[k * stride] = c; }
+};
+
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
 // object/csg/mod.rs:57-106).  `collect` is wave-uniform.
 template <bool HAS_CSG>
-DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect, Walk& w, double* cont_t,
-                  uint32_t* cont_pos, uint32_t& flops, bool count, uint32_t& err) {
+DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect, bool record, Walk& w, ContBuf cb,
+                  uint32_t& flops, bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
     const uint32_t n = S.n_units;
     const double* streamd = (const double*)S.stream;
@@ -360,15 +379,20 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
     int clen = 0, cs_top = 0;
     (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
 
-    auto emit = [&](bool on, double tt, uint32_t p) {
+    // `cls` is the structural-equality class of the leaf at unit position p
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
         if (on) {
             if (collect) {
                 if (tt < w.hit_t || (tt == w.hit_t && w.arrival < w.want_arrival)) {
-                    if (w.n < CONT_CAP) { cont_t[w.n] = tt; cont_pos[w.n] = p; w.n++; } else w.overflow = true;
+                    if (w.n < cb.cap) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
                 }
             } else {
                 if (tt != tt) w.nan_seen = true;
-                if (tt > 0.0 && (w.pos == NONE || tt < w.t)) { w.t = tt; w.pos = p; w.hit_arrival = w.arrival; }
+                const bool below = w.pos == NONE || tt < w.t;
+                if (record && below) {
+                    if (w.n < cb.cap) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
+                }
+                if (tt > 0.0 && below) { w.t = tt; w.pos = p; w.hit_arrival = w.arrival; }
             }
             w.arrival++;
         }
@@ -412,7 +436,8 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
                     if (left_hit) in_left = !in_left; else in_right = !in_right;
                 }
                 if (cs_top == 0) {
-                    for (int a = start; a < wr; a++) emit(true, ct[a], cl[a]);
+                    for (int a = start; a < wr; a++)
+                        emit(true, ct[a], cl[a], (collect || record) ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
                     clen = start;
                 } else {
                     clen = wr;
@@ -427,6 +452,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
             continue;
         }
         const uint32_t w0 = clu(S.stream, i * 16 + 0);
+        const uint32_t w3 = clu(S.stream, i * 16 + 3);
         const uint32_t kind = w0 & 0xFFu;
         if (kind >= K_GROUP) {
             // Group or csg: cull by the stored box (group/mod.rs:30-32, csg/mod.rs:89-91)
@@ -491,7 +517,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
                     on = false;
                 }
             }
-            emit(on, h.t[k], i);
+            emit(on, h.t[k], i, w3);
         }
         i += 2;
     }
@@ -691,45 +717,63 @@ DEV V3 over_point_of(V3 point, V3 normal) { return point + (normal * 100000.0) *
 DEV V3 under_point_of(V3 point, V3 normal) { return point - (normal * 100000.0) * EPS; }
 
 struct N1N2 { double n1, n2; };
-// The container walk of prepare_computations (intersection/mod.rs:62-94) over the collected
-// intersections that sort before the hit, then the hit itself.
-__device__ __noinline__ N1N2 container_walk(const uint32_t* stream, const double* mat, double* ts, uint32_t* poss,
-                                            int n, double hit_t, uint32_t hit_pos) {
-    // stable insertion sort by t (arrival order is the index order)
-    for (int a = 1; a < n; a++) {
-        double ta = ts[a];
-        uint32_t la = poss[a];
-        int b = a - 1;
-        while (b >= 0 && ts[b] > ta) { ts[b + 1] = ts[b]; poss[b + 1] = poss[b]; b--; }
-        ts[b + 1] = ta; poss[b + 1] = la;
-    }
-    uint32_t cont[CONT_CAP + 1];
-    int cn = 0;
-    uint32_t hit_cls = stream[(size_t)hit_pos * 16 + 3];
-    N1N2 r;
-    r.n1 = __builtin_nan("");
-    r.n2 = __builtin_nan("");
-    for (int a = 0; a <= n; a++) {
-        double t = a < n ? ts[a] : hit_t;
-        uint32_t lf = a < n ? poss[a] : hit_pos;
-        uint32_t cls = stream[(size_t)lf * 16 + 3];
-        bool is_hit = (a == n) || (cls == hit_cls && approx_eq(t, hit_t));
-        if (is_hit) r.n1 = cn == 0 ? 1.0 : mat[(size_t)stream[(size_t)cont[cn - 1] * 16 + 1] * 8 + 6];
-        int k = 0;
-        for (; k < cn; k++)
-            if (stream[(size_t)cont[k] * 16 + 3] == cls) break;
-        if (k < cn) {
-            for (int j = k; j + 1 < cn; j++) cont[j] = cont[j + 1];
-            cn--;
-        } else {
-            cont[cn++] = lf;
+// The container walk of prepare_computations (intersection/mod.rs:62-94).  `cb` holds n candidate
+// intersections in arrival order; those with t < hit_t sort before the hit (an equal t arrived
+// after it).  Objects are compared by class id, which stands for the reference's structural `==`.
+// The containers list is built in place over the entries already consumed.
+DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, int n, double hit_t, uint32_t hit_pos,
+                        uint32_t hit_cls) {
+    const int S = cb.stride;
+    int m = 0;
+    for (int a = 0; a < n; a++) {
+        double ta = cb.t[a * S];
+        if (ta < hit_t) {
+            if (m != a) cb.put(m, ta, cb.pos[a * S], cb.cls[a * S]);
+            m++;
         }
+    }
+    // stable insertion sort by t (List::sort, intersection/list.rs:39-50)
+    for (int a = 1; a < m; a++) {
+        double ta = cb.t[a * S];
+        if (!(cb.t[(a - 1) * S] > ta)) continue;
+        uint32_t la = cb.pos[a * S], ca = cb.cls[a * S];
+        int b = a - 1;
+        while (b >= 0 && cb.t[b * S] > ta) { cb.put(b + 1, cb.t[b * S], cb.pos[b * S], cb.cls[b * S]); b--; }
+        cb.put(b + 1, ta, la, ca);
+    }
+    int cn = 0;  // containers are entries [0, cn) of pos/cls, oldest first; cn <= a
+    uint32_t n1_pos = NONE, n2_pos = NONE;
+    for (int a = 0; a <= m; a++) {
+        double t = hit_t;
+        uint32_t lf = hit_pos, cls = hit_cls;
+        if (a < m) { t = cb.t[a * S]; lf = cb.pos[a * S]; cls = cb.cls[a * S]; }
+        const bool is_hit = (a == m) || (cls == hit_cls && approx_eq(t, hit_t));
+        int k = 0;
+        while (k < cn && cb.cls[k * S] != cls) k++;
         if (is_hit) {
-            r.n2 = cn == 0 ? 1.0 : mat[(size_t)stream[(size_t)cont[cn - 1] * 16 + 1] * 8 + 6];
+            n1_pos = cn == 0 ? NONE : cb.pos[(cn - 1) * S];
+            if (k == cn) n2_pos = lf;                                   // appended: the hit object itself
+            else if (k < cn - 1) n2_pos = cb.pos[(cn - 1) * S];         // removed below the top
+            else n2_pos = cn >= 2 ? cb.pos[(cn - 2) * S] : NONE;        // the top was removed
             break;
         }
+        if (k < cn) {
+            for (int j = k; j + 1 < cn; j++) { cb.pos[j * S] = cb.pos[(j + 1) * S]; cb.cls[j * S] = cb.cls[(j + 1) * S]; }
+            cn--;
+        } else {
+            cb.pos[cn * S] = lf; cb.cls[cn * S] = cls; cn++;
+        }
     }
+    N1N2 r;
+    r.n1 = n1_pos == NONE ? 1.0 : mat[(size_t)stream[(size_t)n1_pos * 16 + 1] * 8 + 6];
+    r.n2 = n2_pos == NONE ? 1.0 : mat[(size_t)stream[(size_t)n2_pos * 16 + 1] * 8 + 6];
     return r;
+}
+// Lane-private scratch buffers make this one big; keep it out of line.
+__device__ __noinline__ N1N2 container_walk_scratch(const uint32_t* stream, const double* mat, double* ts, uint32_t* poss,
+                                                    uint32_t* clss, int n, double hit_t, uint32_t hit_pos, uint32_t hit_cls) {
+    ContBuf cb = {ts, poss, clss, 1, CONT_CAP};
+    return container_walk(stream, mat, cb, n, hit_t, hit_pos, hit_cls);
 }
 
 // Computations::schlick (intersection/computations.rs:28-45); powi(5) = x*((x*x)*(x*x)).
@@ -810,36 +854,61 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         ray.d = mk(q->dx, q->dy, q->dz);
     }
 
-    double cont_t[CONT_CAP];
-    uint32_t cont_pos[CONT_CAP];
+    __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
+    __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
+    const ContBuf fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
     Walk w;
     w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
     w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
-    // job 0: closest hit
-    traverse<HAS_CSG>(S, ray, on, false, w, cont_t, cont_pos, flops, true, err);
+    // closest hit; scenes with a transparent material also record what may sort before it
+    const bool record = (S.flags & 1u) != 0;
+    traverse<HAS_CSG>(S, ray, on, false, record, w, fast, flops, true, err);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
     const double hit_t = w.t;
     const uint32_t hit_pos = w.pos;
+    const uint32_t hit_cls = hit ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
     const double* mat_rec = S.mat + (hit ? (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 : 0);
     const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
-    // job 1: for refractive hits, the intersections that sort before the hit -> n1, n2
+    // for refractive hits: the intersections that sort before the hit -> n1, n2
     double n1 = 1.0, n2 = 1.0;
     const bool need_cont = hit && (!approx0(m_transparency) || m_transparency > 0.0);
-    if (__ballot(need_cont) != 0ull) {
-        w.hit_t = hit_t; w.want_arrival = w.hit_arrival; w.arrival = 0; w.n = 0; w.overflow = false;
+    const bool slow = need_cont && (w.overflow || !record);
+    if (__ballot(slow) != 0ull) {
+        // the recorded list overflowed: a collecting walk into the big lane-private buffer
+        double cont_t[CONT_CAP];
+        uint32_t cont_pos[CONT_CAP], cont_cls[CONT_CAP];
+        const ContBuf big = {cont_t, cont_pos, cont_cls, 1, CONT_CAP};
+        Walk w2 = w;
+        w2.hit_t = hit_t; w2.want_arrival = w.hit_arrival; w2.arrival = 0; w2.n = 0; w2.overflow = false;
         uint32_t unused = 0;
-        traverse<HAS_CSG>(S, ray, need_cont, true, w, cont_t, cont_pos, unused, false, err);
-        if (need_cont) {
-            if (w.overflow) err |= 2u;
-            N1N2 nn = container_walk(S.stream, S.mat, cont_t, cont_pos, w.n, hit_t, hit_pos);
+        traverse<HAS_CSG>(S, ray, slow, true, false, w2, big, unused, false, err);
+        if (slow) {
+            if (w2.overflow) err |= 2u;
+            N1N2 nn = container_walk_scratch(S.stream, S.mat, cont_t, cont_pos, cont_cls, w2.n, hit_t, hit_pos, hit_cls);
             n1 = nn.n1; n2 = nn.n2;
         }
     }
+    if (need_cont && !slow) {
+        N1N2 nn = container_walk(S.stream, S.mat, fast, w.n, hit_t, hit_pos, hit_cls);
+        n1 = nn.n1; n2 = nn.n2;
+#ifdef EXP_CONT2
+        nn = container_walk(S.stream, S.mat, fast, 0, hit_t, hit_pos, hit_cls);
+        if (nn.n1 == 77.0) n2 = 7.0;
+#endif
+    }
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
     if (hit) {
+#ifndef EXP_NO_GEOM
         HitGeom g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
         point = g.point; normal = g.normal;
+#ifdef EXP_GEOM2
+        g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
+        if (g.point.x != point.x) normal.x = 3.0;
+#endif
+#else
+        point = ray.o + ray.d * hit_t; normal = normalise(mk(ray.d.y, -ray.d.x + 0.1, 0.3));
+#endif
         flops += F_PREPARE;
     }
     const V3 eye = -ray.d;
@@ -907,7 +976,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
             } else err |= 1u;
         }
     }
+#ifdef EXP_NO_STORE
+    if (on && hit_t == 123.456) {
+#else
     if (on) {
+#endif
         NodeRec* r = A.recs + rec_idx;
         r->r = 0.0; r->g = 0.0; r->b = 0.0;
         r->reflective = hit ? m_reflective : 0.0;
@@ -984,7 +1057,7 @@ __global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S
                 Walk w;
                 w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
                 w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
-                traverse<HAS_CSG>(S, sr, on, false, w, nullptr, nullptr, flops, true, err);
+                traverse<HAS_CSG>(S, sr, on, false, false, w, ContBuf{nullptr, nullptr, nullptr, 1, 0}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
                 bool shadowed = false;
                 if (on && w.pos != NONE) {
@@ -1182,8 +1255,9 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const Ray
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
     int inside = 0;
     double n1 = 1.0, n2 = 1.0;
-    double cont_t[CONT_CAP];
-    uint32_t cont_pos[CONT_CAP];
+    __shared__ double s_rec_t[REC_CAP * 256];
+    __shared__ uint32_t s_rec_pos[REC_CAP * 256], s_rec_cls[REC_CAP * 256];
+    const ContBuf fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, 256, REC_CAP};
     Walk w;
     bool hit = false, need = false;
     double hit_t = 0.0;
@@ -1192,26 +1266,45 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const Ray
     uint32_t n_l = S.n_lights < 4 ? S.n_lights : 4;
     for (uint32_t job = 0; job < 2 + n_l; job++) {
         Ray jr = ray;
-        bool jon = on, collect = false;
+        bool jon = on;
         double dist = 0.0;
         if (job == 1) {
-            if (__ballot(need) == 0ull) continue;
-            jon = need; collect = true;
-            w.hit_t = hit_t; w.want_arrival = w.hit_arrival; w.arrival = 0; w.n = 0; w.overflow = false;
-        } else {
-            if (job >= 2) {
-                uint32_t l = job - 2;
-                V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
-                V3 over = over_point_of(point, normal);
-                V3 vec = lpos - over;
-                dist = sqrt(dot(vec, vec));
-                jr.o = over;
-                jr.d = normalise(vec);
-                jon = hit;
+            // n1 / n2 from the recorded candidates, or from a collecting walk where they overflowed
+            const uint32_t hit_cls = need ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
+            const bool slow = need && w.overflow;
+            if (__ballot(slow) != 0ull) {
+                double cont_t[CONT_CAP];
+                uint32_t cont_pos[CONT_CAP], cont_cls[CONT_CAP];
+                const ContBuf big = {cont_t, cont_pos, cont_cls, 1, CONT_CAP};
+                Walk w2 = w;
+                w2.hit_t = hit_t; w2.want_arrival = w.hit_arrival; w2.arrival = 0; w2.n = 0; w2.overflow = false;
+                traverse<HAS_CSG>(S, jr, slow, true, false, w2, big, flops, false, err);
+                if (slow) {
+                    if (w2.overflow) err |= 2u;
+                    N1N2 nn = container_walk_scratch(S.stream, S.mat, cont_t, cont_pos, cont_cls, w2.n, hit_t, hit_pos, hit_cls);
+                    n1 = nn.n1; n2 = nn.n2;
+                }
             }
-            w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
+            if (need && !slow) {
+                N1N2 nn = container_walk(S.stream, S.mat, fast, w.n, hit_t, hit_pos, hit_cls);
+                n1 = nn.n1; n2 = nn.n2;
+            }
+            continue;
         }
-        traverse<HAS_CSG>(S, jr, jon, collect, w, cont_t, cont_pos, flops, false, err);
+        if (job >= 2) {
+            uint32_t l = job - 2;
+            V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+            V3 over = over_point_of(point, normal);
+            V3 vec = lpos - over;
+            dist = sqrt(dot(vec, vec));
+            jr.o = over;
+            jr.d = normalise(vec);
+            jon = hit;
+        } else {
+            w.n = 0; w.overflow = false;
+        }
+        w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
+        traverse<HAS_CSG>(S, jr, jon, false, job == 0, w, fast, flops, false, err);
         if (job == 0) {
             if (w.nan_seen && w.arrival >= 2) err |= 4u;
             hit = on && w.pos != NONE;
@@ -1222,12 +1315,6 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const Ray
             }
             double tr = hit ? S.mat[(size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 + 5] : 0.0;
             need = hit && (!approx0(tr) || tr > 0.0);
-        } else if (job == 1) {
-            if (need) {
-                if (w.overflow) err |= 2u;
-                N1N2 nn = container_walk(S.stream, S.mat, cont_t, cont_pos, w.n, hit_t, hit_pos);
-                n1 = nn.n1; n2 = nn.n2;
-            }
         } else {
             bool s = false;
             if (hit && w.pos != NONE) s = ((S.stream[(size_t)w.pos * 16] >> 8) & 1u) && w.t < dist;
@@ -1728,6 +1815,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->dev.n_units = units; s->dev.n_lights = d->n_lights;
     s->dev.class_words = (uint32_t)words;
     s->dev.draws_per_shade = (uint32_t)draws;
+    s->dev.flags = 0;
+    for (uint32_t i = 0; i < d->n_materials; i++)
+        if (d->material[(size_t)i * 7 + 5] != 0.0) s->dev.flags |= 1u;
     UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
     UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);
     UP(light_meta, light_meta);
