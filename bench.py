@@ -173,8 +173,7 @@ def main():
                 "other_kernels": {
                     "k_shadow": {"ms_per_frame": stats["ms_shadow"], "algorithmic_flop_per_frame": stats["flop_shadow"],
                                  "achieved_TFLOPs": stats["flop_shadow"] / (stats["ms_shadow"] * 1e-3) / 1e12 if stats["ms_shadow"] > 0 else 0.0},
-                    "k_light": {"ms_per_frame": stats["ms_light"], "algorithmic_flop_per_frame": stats["flop_light"]},
-                    "k_combine": {"ms_per_frame": stats["ms_combine"]},
+                    "k_shade": {"ms_per_frame": stats["ms_shade"], "algorithmic_flop_per_frame": stats["flop_light"]},
                 },
                 "hbm": {"algorithmic_bytes_per_frame": alg_bytes,
                         "achieved_GBs_over_frame": alg_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -10,7 +10,7 @@
  * together with everything that call runs per pixel (World::colour_at and
  * below, src/world.rs:33-177).  The reference has no FFI of its own; these
  * entry points are what an `extern "C"` block in a Rust `-sys` crate would
- * bind (the stub is shown in INTEGRATION.md).  All arguments are plain
+ * bind.  All arguments are plain
  * pointers and sizes.  Every function returns 0 on success and a negative
  * code otherwise; the message is available from rt_last_error() on the
  * calling thread.  The caller owns every buffer it passes; the library owns
@@ -140,12 +140,12 @@ typedef struct rt_stats {
     double ms_trace;         /* summed HIP-event durations of the k_trace launches
                                 (closest hit + n1/n2 + spawn, one per level)       */
     double ms_shadow;        /* k_shadow launches (shadow rays, one per chunk)     */
-    double ms_light;         /* k_light launches (patterns + Phong, one per chunk) */
-    double ms_combine;       /* the bottom-up fold                                 */
+    double ms_shade;         /* k_shade launches (patterns + Phong + the sum with
+                                the spawned rays' colours, one per level)          */
     uint64_t trace_launches; /* number of k_trace launches                         */
     uint64_t flop_trace;     /* algorithmic f64 FLOP counted on the device in
-                                k_trace / k_shadow / k_light: op-class counts x the
-                                per-op constants stated in DESIGN.md               */
+                                k_trace / k_shadow / k_shade: op-class counts x the
+                                per-op constants F_* of csrc/rt_device.hip         */
     uint64_t flop_shadow;
     uint64_t flop_light;
 } rt_stats;

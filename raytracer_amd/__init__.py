@@ -49,8 +49,8 @@ class Stats(C.Structure):
     _fields_ = [
         ("primary_rays", C.c_uint64), ("secondary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
         ("shade_hits", C.c_uint64), ("levels", C.c_uint32), ("chunks", C.c_uint32),
-        ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_light", C.c_double),
-        ("ms_combine", C.c_double), ("trace_launches", C.c_uint64), ("flop_trace", C.c_uint64),
+        ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
+        ("trace_launches", C.c_uint64), ("flop_trace", C.c_uint64),
         ("flop_shadow", C.c_uint64), ("flop_light", C.c_uint64),
     ]
 

@@ -132,7 +132,7 @@ struct DevScene {
 // reference's formulas); the device sums them per lane actually tested.
 constexpr uint32_t F_XFORM = 33, F_SPHERE = 32, F_PLANE = 3, F_BOX = 16, F_CYL = 40, F_CONE = 46, F_TRI = 45,
                    F_PRIMARY = 50, F_PREPARE = 95, F_LIGHT = 45, F_SHADOW = 14, F_SCHLICK = 20, F_REFRACT = 25,
-                   F_PATTERN = 18;
+                   F_PATTERN = 18, F_COMBINE = 12;
 
 // ---------------------------------------------------------------- wave helpers
 DEV uint32_t wave_min_u32(uint32_t v) {
@@ -590,29 +590,24 @@ DEV V3 pattern_eval(PatTables S, uint32_t root, V3 object_point) {
 }
 
 // ---------------------------------------------------------------- per-level work
-struct RayRec {  // 64 B queue entry
-    double ox, oy, oz, dx, dy, dz;
-    uint32_t pad[4];
+// One record per traced ray, kept as a structure of arrays over the records of a chunk so that a
+// wave's loads and stores are contiguous.  The levels of the recursion occupy consecutive index
+// ranges; a spawned ray is written straight into its own record.
+struct Recs {
+    double *ox, *oy, *oz, *dx, *dy, *dz;  // the ray (primary rays store the direction only)
+    double *px, *py, *pz;                  // over_point of the hit
+    double *nx, *ny, *nz;                  // normal at the hit
+    double *reflectance;                   // schlick value, where the material is reflective and transparent
+    double *r, *g, *b;                     // colour_at of the ray, filled bottom-up
+    uint32_t *hit_pos;                     // unit position of the hit leaf, NONE for a miss
+    uint32_t *child_refl, *child_refr;     // record of the spawned rays or NONE (valid for hits)
+    uint32_t *order;                       // area lights: subtree size, then position in the row's rng order
 };
-struct NodeRec {  // 64 B: one per traced ray
-    double r, g, b;              // surface colour, later the folded colour
-    double reflective, transparency;
-    double reflectance;          // schlick value, or < 0 when the plain sum applies
-    uint32_t child_refl, child_refr;  // record indices or NONE
-    uint32_t hit;                // 1 when the ray hit something (a shade point)
-    uint32_t order;              // deferred shading: subtree size, then position in the row's rng order
-};
-struct TaskRec {  // 80 B: shading input for one shade point, parallel to NodeRec
-    double px, py, pz;   // over_point
-    double nx, ny, nz;   // normal
-    double dx, dy, dz;   // ray direction (eye = -direction)
-    uint32_t pos;        // unit position of the hit leaf
-    uint32_t pad;
-};
+constexpr size_t REC_BYTES = 16 * sizeof(double) + 4 * sizeof(uint32_t);
 
 struct Counters {  // per-level control words, read back by the host after every k_trace launch
     uint32_t next_count;  // rays appended to the next level
-    uint32_t error;       // bit0 queue/record overflow, bit1 list overflow, bit2 NaN distance
+    uint32_t error;       // bit0 record arrays full, bit1 list overflow, bit2 NaN distance
 };
 // Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
 // and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
@@ -622,25 +617,23 @@ struct __attribute__((aligned(64))) StatShard {
 };
 
 struct LevelArgs {
-    // rays of this level
-    uint32_t n_rays;          // level >= 1 (and caller-supplied rays)
-    const RayRec* in_rays;
+    uint32_t n_rays;          // rays of this level (k_trace, k_shade) or records of the chunk (k_shadow)
     // primary mode: tile geometry of the chunk
     uint32_t width, chunk_row0, chunk_rows, tiles_x, n_tiles;
     uint32_t part_block, part_rank, part_world;  // row partition (global y of a local row)
     double cam_inv[12];
     double half_width, half_height, pixel_size;
-    // outputs
-    NodeRec* recs;            // records of the whole chunk
-    TaskRec* tasks;           // shading inputs, parallel to recs
-    double* intensity;        // n_lights values per record: Lightable::intensity_at
+    Recs R;                   // records of the whole chunk
+    double* intensity;        // Lightable::intensity_at of light l for record i at [l * rec_cap + i]
     const Rng* rng_states;    // area lights only: one generator state per shade point of the chunk
     uint32_t rec_base;        // first record of this level
     uint32_t next_rec_base;   // first record of the next level
-    RayRec* out_rays;
-    uint32_t out_cap;         // capacity of out_rays
-    uint32_t rec_cap;         // capacity of recs
+    uint32_t rec_cap;         // capacity of the record arrays
     uint32_t depth_remaining; // the reference's `depth` argument at this level
+    // frame buffers (level 0 of k_shade), indexed from out_offset
+    double* out_rgb;
+    uint8_t* out_rgb8;
+    size_t out_offset;
     Counters* counters;
     StatShard* stats;
 };
@@ -844,14 +837,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         rec_idx = on ? ly * A.width + x : 0;
         uint32_t gy = global_row(A, A.chunk_row0 + (on ? ly : 0));
         ray = ray_for_pixel(A, on ? x : 0, gy);
-        if (on) flops += F_PRIMARY;
+        if (on) {
+            flops += F_PRIMARY;
+            A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
+        }
     } else {
         uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
         on = idx < A.n_rays;
         rec_idx = A.rec_base + (on ? idx : 0);
-        const RayRec* q = A.in_rays + (on ? idx : 0);
-        ray.o = mk(q->ox, q->oy, q->oz);
-        ray.d = mk(q->dx, q->dy, q->dz);
+        ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
+        ray.d = mk(A.R.dx[rec_idx], A.R.dy[rec_idx], A.R.dz[rec_idx]);
     }
 
     __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
@@ -956,46 +951,32 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[k];
         unsigned long long below = (1ull << lane) - 1ull;
         if (spawn_refl) {
-            uint32_t slot = base + __popcll(b_refl & below);
-            if (slot < A.out_cap && A.next_rec_base + slot < A.rec_cap) {
+            uint32_t c = A.next_rec_base + base + __popcll(b_refl & below);
+            if (c < A.rec_cap) {
                 V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
-                RayRec* o = A.out_rays + slot;
-                o->ox = over.x; o->oy = over.y; o->oz = over.z;
-                o->dx = d_.x; o->dy = d_.y; o->dz = d_.z;
-                child_refl = A.next_rec_base + slot;
+                A.R.ox[c] = over.x; A.R.oy[c] = over.y; A.R.oz[c] = over.z;
+                A.R.dx[c] = d_.x; A.R.dy[c] = d_.y; A.R.dz[c] = d_.z;
+                child_refl = c;
             } else err |= 1u;
         }
         if (spawn_refr) {
-            uint32_t slot = base + n_refl + __popcll(b_refr & below);
-            if (slot < A.out_cap && A.next_rec_base + slot < A.rec_cap) {
+            uint32_t c = A.next_rec_base + base + n_refl + __popcll(b_refr & below);
+            if (c < A.rec_cap) {
                 V3 o_ = under_point_of(point, normal);
-                RayRec* o = A.out_rays + slot;
-                o->ox = o_.x; o->oy = o_.y; o->oz = o_.z;
-                o->dx = refr_dir.x; o->dy = refr_dir.y; o->dz = refr_dir.z;
-                child_refr = A.next_rec_base + slot;
+                A.R.ox[c] = o_.x; A.R.oy[c] = o_.y; A.R.oz[c] = o_.z;
+                A.R.dx[c] = refr_dir.x; A.R.dy[c] = refr_dir.y; A.R.dz[c] = refr_dir.z;
+                child_refr = c;
             } else err |= 1u;
         }
     }
-#ifdef EXP_NO_STORE
-    if (on && hit_t == 123.456) {
-#else
     if (on) {
-#endif
-        NodeRec* r = A.recs + rec_idx;
-        r->r = 0.0; r->g = 0.0; r->b = 0.0;
-        r->reflective = hit ? m_reflective : 0.0;
-        r->transparency = hit ? m_transparency : 0.0;
-        r->reflectance = reflectance;
-        r->child_refl = child_refl;
-        r->child_refr = child_refr;
-        r->hit = hit ? 1u : 0u;
-        r->order = 0;
+        A.R.hit_pos[rec_idx] = hit ? hit_pos : NONE;
         if (hit) {
-            TaskRec* t = A.tasks + rec_idx;
-            t->px = over.x; t->py = over.y; t->pz = over.z;
-            t->nx = normal.x; t->ny = normal.y; t->nz = normal.z;
-            t->dx = ray.d.x; t->dy = ray.d.y; t->dz = ray.d.z;
-            t->pos = hit_pos;
+            A.R.px[rec_idx] = over.x; A.R.py[rec_idx] = over.y; A.R.pz[rec_idx] = over.z;
+            A.R.nx[rec_idx] = normal.x; A.R.ny[rec_idx] = normal.y; A.R.nz[rec_idx] = normal.z;
+            A.R.child_refl[rec_idx] = child_refl;
+            A.R.child_refr[rec_idx] = child_refr;
+            if (reflectance >= 0.0) A.R.reflectance[rec_idx] = reflectance;
         }
     }
 
@@ -1024,13 +1005,11 @@ __global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool on = idx < A.n_rays;
     const uint32_t rec_idx = on ? idx : 0;
-    const NodeRec* nr = A.recs + rec_idx;
-    on = on && nr->hit != 0;
-    const TaskRec* q = A.tasks + rec_idx;
-    const V3 over = on ? mk(q->px, q->py, q->pz) : mk(0.0, 0.0, 0.0);
+    on = on && A.R.hit_pos[rec_idx] != NONE;
+    const V3 over = on ? mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]) : mk(0.0, 0.0, 0.0);
     Rng rng;
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    if (A.rng_states && on) rng = A.rng_states[nr->order];
+    if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
     uint32_t flops = 0, err = 0, n_shadow = 0;
     if (__ballot(on) != 0ull) {
         for (uint32_t l = 0; l < S.n_lights; l++) {
@@ -1069,7 +1048,7 @@ __global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S
             }
             if (on) {
                 double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
-                A.intensity[(size_t)rec_idx * S.n_lights + l] = intensity;
+                A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
             }
             if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
         }
@@ -1085,70 +1064,6 @@ __global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S
     if (any_err && err) atomicOr(&A.counters->error, err);
 }
 
-// The surface colour of every shade point: Σ over lights of Material::lighting (world.rs:58-70,
-// material.rs:47-87) with pattern_at(object, over_point) (pattern/mod.rs:83-87).
-__global__ __launch_bounds__(256) void k_light(DevScene S, LevelArgs A) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t flops = 0;
-    if (idx < A.n_rays && A.recs[idx].hit) {
-    NodeRec* nr = A.recs + idx;
-    const TaskRec* q = A.tasks + idx;
-    const V3 over = mk(q->px, q->py, q->pz), normal = mk(q->nx, q->ny, q->nz);
-    const V3 eye = -mk(q->dx, q->dy, q->dz);
-    const uint32_t hit_pos = q->pos;
-    const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
-    const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
-    V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
-    PatTables pt;
-    pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
-    const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
-    Rng rng;
-    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    if (A.rng_states) rng = A.rng_states[nr->order];
-    V3 surface = mk(0.0, 0.0, 0.0);
-    flops = F_PATTERN;
-    for (uint32_t l = 0; l < S.n_lights; l++) {
-        const uint32_t usteps = S.light_meta[l * 4 + 1], vsteps = S.light_meta[l * 4 + 2];
-        const uint32_t samples = usteps * vsteps;
-        const bool is_area = S.light_meta[l * 4 + 0] == RT_LIGHT_AREA;
-        const double* ld = S.light + (size_t)l * 12;
-        const V3 l0 = mk(ld[0], ld[1], ld[2]), uc = mk(ld[3], ld[4], ld[5]), vc = mk(ld[6], ld[7], ld[8]);
-        const V3 lint = is_area ? mk(ld[9], ld[10], ld[11]) : uc;
-        const double intensity = A.intensity[(size_t)idx * S.n_lights + l];
-        if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
-        V3 colour = cmul(pat, lint);
-        V3 ambient = colour * m_ambient;
-        V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
-        for (uint32_t k = 0; k < samples; k++) {
-            V3 lp = l0;
-            if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
-                double r1 = rng_unit(rng);
-                V3 p = l0 + uc * ((double)(k % usteps) + r1);
-                double r2 = rng_unit(rng);
-                lp = p + vc * ((double)(k / usteps) + r2);
-            }
-            V3 lv = normalise(lp - over);
-            double ldn = dot(lv, normal);
-            if (ldn >= 0.0) {
-                diffuse = diffuse + (colour * m_diffuse) * ldn;
-                V3 rv = -reflect(lv, normal);
-                double rde = dot(rv, eye);
-                if (rde > 0.0) {
-                    double factor = pow(rde, m_shininess);
-                    specular = specular + (lint * m_specular) * factor;
-                }
-            }
-        }
-        surface = surface + (ambient + ((diffuse + specular) / (double)samples) * intensity);
-        flops += F_LIGHT * samples;
-    }
-    nr->r = surface.x; nr->g = surface.y; nr->b = surface.z;
-    }
-    uint32_t s_lo = wave_sum_u32(flops & 0xFFFFu), s_hi = wave_sum_u32(flops >> 16);
-    if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
-        atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
-}
-
 // Colour::to_u8 (colour.rs:63-72): clamp, * 255, round half away from zero, NaN -> 0.
 DEV uint8_t to_u8(double c) {
     if (c != c) return 0;
@@ -1156,73 +1071,144 @@ DEV uint8_t to_u8(double c) {
     return (uint8_t)round(cl * 255.0);
 }
 
-// Fold one level of records bottom-up (world.rs:72-86,144,176).  With
-// output pointers (level 0) the folded colour also goes to the frame buffers.
-__global__ __launch_bounds__(256) void k_combine(NodeRec* recs, uint32_t base, uint32_t n, double* out_rgb,
-                                                 uint8_t* out_rgb8, size_t out_offset) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    NodeRec* r = recs + base + i;
-    V3 surface = mk(r->r, r->g, r->b);
-    V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
-    uint32_t cr = r->child_refl, ct = r->child_refr;
-    if (cr != NONE) reflected = mk(recs[cr].r, recs[cr].g, recs[cr].b) * r->reflective;
-    if (ct != NONE) refracted = mk(recs[ct].r, recs[ct].g, recs[ct].b) * r->transparency;
-    double R = r->reflectance;
-    V3 colour = R >= 0.0 ? surface + reflected * R + refracted * (1.0 - R) : surface + reflected + refracted;
-    r->r = colour.x; r->g = colour.y; r->b = colour.z;
-    if (out_rgb) {
-        double* o = out_rgb + (out_offset + i) * 3;
-        o[0] = colour.x; o[1] = colour.y; o[2] = colour.z;
+// colour_at of every ray of one level, deepest level first: the surface colour, Σ over lights of
+// Material::lighting (world.rs:58-70, material.rs:47-87) with pattern_at(object, over_point)
+// (pattern/mod.rs:83-87), plus the colours of the spawned rays (world.rs:72-86,144,176).  No tree
+// walk here, so the register-hungry pow() stays out of the walking kernels' allocation.  Level 0
+// writes the frame buffers instead of the record.
+__global__ __launch_bounds__(256) void k_shade(DevScene S, LevelArgs A) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool on = idx < A.n_rays;
+    const uint32_t rec = A.rec_base + (on ? idx : 0);
+    const uint32_t hit_pos = on ? A.R.hit_pos[rec] : NONE;
+    uint32_t flops = 0;
+    V3 colour = mk(0.0, 0.0, 0.0);
+    if (hit_pos != NONE) {
+        const V3 over = mk(A.R.px[rec], A.R.py[rec], A.R.pz[rec]), normal = mk(A.R.nx[rec], A.R.ny[rec], A.R.nz[rec]);
+        const V3 eye = -mk(A.R.dx[rec], A.R.dy[rec], A.R.dz[rec]);
+        const uint32_t cr = A.R.child_refl[rec], ct = A.R.child_refr[rec];
+        const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
+        const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
+        const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
+        V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
+        PatTables pt;
+        pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+        const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
+        Rng rng;
+        rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+        if (A.rng_states) rng = A.rng_states[A.R.order[rec]];
+        V3 surface = mk(0.0, 0.0, 0.0);
+        flops = F_PATTERN;
+        for (uint32_t l = 0; l < S.n_lights; l++) {
+            const uint32_t usteps = S.light_meta[l * 4 + 1], vsteps = S.light_meta[l * 4 + 2];
+            const uint32_t samples = usteps * vsteps;
+            const bool is_area = S.light_meta[l * 4 + 0] == RT_LIGHT_AREA;
+            const double* ld = S.light + (size_t)l * 12;
+            const V3 l0 = mk(ld[0], ld[1], ld[2]), uc = mk(ld[3], ld[4], ld[5]), vc = mk(ld[6], ld[7], ld[8]);
+            const V3 lint = is_area ? mk(ld[9], ld[10], ld[11]) : uc;
+            const double intensity = A.intensity[(size_t)l * A.rec_cap + rec];
+            if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
+            V3 col = cmul(pat, lint);
+            V3 ambient = col * m_ambient;
+            V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
+            for (uint32_t k = 0; k < samples; k++) {
+                V3 lp = l0;
+                if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
+                    double r1 = rng_unit(rng);
+                    V3 p = l0 + uc * ((double)(k % usteps) + r1);
+                    double r2 = rng_unit(rng);
+                    lp = p + vc * ((double)(k / usteps) + r2);
+                }
+                V3 lv = normalise(lp - over);
+                double ldn = dot(lv, normal);
+                if (ldn >= 0.0) {
+                    diffuse = diffuse + (col * m_diffuse) * ldn;
+                    V3 rv = -reflect(lv, normal);
+                    double rde = dot(rv, eye);
+                    if (rde > 0.0) {
+                        double factor = pow(rde, m_shininess);
+                        specular = specular + (lint * m_specular) * factor;
+                    }
+                }
+            }
+            surface = surface + (ambient + ((diffuse + specular) / (double)samples) * intensity);
+            flops += F_LIGHT * samples;
+        }
+        // shade_hit's sum (world.rs:72-86); a ray that was not spawned contributes black
+        V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
+        if (cr != NONE) reflected = mk(A.R.r[cr], A.R.g[cr], A.R.b[cr]) * m_reflective;
+        if (ct != NONE) refracted = mk(A.R.r[ct], A.R.g[ct], A.R.b[ct]) * m_transparency;
+        if (m_reflective > 0.0 && m_transparency > 0.0) {
+            const double Rf = A.R.reflectance[rec];
+            colour = surface + reflected * Rf + refracted * (1.0 - Rf);
+            flops += F_COMBINE + 7;
+        } else {
+            colour = surface + reflected + refracted;
+            flops += F_COMBINE;
+        }
     }
-    if (out_rgb8) {
-        uint8_t* o = out_rgb8 + (out_offset + i) * 3;
-        o[0] = to_u8(colour.x); o[1] = to_u8(colour.y); o[2] = to_u8(colour.z);
+    if (on) {
+        if (A.out_rgb || A.out_rgb8) {
+            if (A.out_rgb) {
+                double* o = A.out_rgb + (A.out_offset + idx) * 3;
+                o[0] = colour.x; o[1] = colour.y; o[2] = colour.z;
+            }
+            if (A.out_rgb8) {
+                uint8_t* o = A.out_rgb8 + (A.out_offset + idx) * 3;
+                o[0] = to_u8(colour.x); o[1] = to_u8(colour.y); o[2] = to_u8(colour.z);
+            }
+        } else {
+            A.R.r[rec] = colour.x; A.R.g[rec] = colour.y; A.R.b[rec] = colour.z;
+        }
     }
+    uint32_t s_lo = wave_sum_u32(flops & 0xFFFFu), s_hi = wave_sum_u32(flops >> 16);
+    if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
+        atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
 // after pixel, and inside a pixel depth-first with the reflected subtree before the refracted one
 // (camera.rs:143-157, world.rs:60-74).
 // (1) bottom-up: order = number of shade points in the subtree
-__global__ __launch_bounds__(256) void k_order_sizes(NodeRec* recs, uint32_t base, uint32_t n) {
+__global__ __launch_bounds__(256) void k_order_sizes(Recs R, uint32_t base, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    NodeRec* r = recs + base + i;
+    const uint32_t rec = base + i;
     uint32_t s = 0;
-    if (r->hit) {
+    if (R.hit_pos[rec] != NONE) {
         s = 1;
-        if (r->child_refl != NONE) s += recs[r->child_refl].order;
-        if (r->child_refr != NONE) s += recs[r->child_refr].order;
+        const uint32_t cr = R.child_refl[rec], ct = R.child_refr[rec];
+        if (cr != NONE) s += R.order[cr];
+        if (ct != NONE) s += R.order[ct];
     }
-    r->order = s;
+    R.order[rec] = s;
 }
 // (2) one lane per row: running offsets of the row's pixels; row_total[row] = shade points in the row
-__global__ __launch_bounds__(64) void k_order_rows(NodeRec* recs, uint32_t width, uint32_t rows, uint32_t* pixel_base,
+__global__ __launch_bounds__(64) void k_order_rows(Recs R, uint32_t width, uint32_t rows, uint32_t* pixel_base,
                                                    uint32_t* row_total) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= rows) return;
     uint32_t acc = 0;
     for (uint32_t x = 0; x < width; x++) {
         pixel_base[(size_t)row * width + x] = acc;
-        acc += recs[(size_t)row * width + x].order;
+        acc += R.order[(size_t)row * width + x];
     }
     row_total[row] = acc;
 }
 // (3) top-down: order = position of the shade point in the chunk's state array
-__global__ __launch_bounds__(256) void k_order_assign(NodeRec* recs, uint32_t base, uint32_t n, uint32_t width,
+__global__ __launch_bounds__(256) void k_order_assign(Recs R, uint32_t base, uint32_t n, uint32_t width,
                                                       const uint32_t* pixel_base, const uint32_t* row_base, int level0) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    NodeRec* r = recs + base + i;
-    if (!r->hit) return;
-    uint32_t mine = r->order;  // level 0: still the subtree size; deeper: already the position
+    const uint32_t rec = base + i;
+    if (R.hit_pos[rec] == NONE) return;
+    uint32_t mine = R.order[rec];  // level 0: still the subtree size; deeper: already the position
     if (level0) mine = row_base[i / width] + pixel_base[i];
     uint32_t next = mine + 1;
-    uint32_t cr = r->child_refl, ct = r->child_refr;
-    if (cr != NONE && recs[cr].hit) { uint32_t sz = recs[cr].order; recs[cr].order = next; next += sz; }
-    if (ct != NONE && recs[ct].hit) recs[ct].order = next;
-    r->order = mine;
+    const uint32_t cr = R.child_refl[rec], ct = R.child_refr[rec];
+    if (cr != NONE && R.hit_pos[cr] != NONE) { uint32_t sz = R.order[cr]; R.order[cr] = next; next += sz; }
+    if (ct != NONE && R.hit_pos[ct] != NONE) R.order[ct] = next;
+    R.order[rec] = mine;
 }
 // (4) one lane per row: step the row's generator, leaving its state at every shade point
 __global__ __launch_bounds__(64) void k_rng_rows(Rng* states, const uint32_t* row_base, const uint32_t* row_total,
@@ -1244,13 +1230,13 @@ __global__ __launch_bounds__(64) void k_rng_rows(Rng* states, const uint32_t* ro
 
 // rt_probe: prepare_computations of the closest hit, for parity checks.
 template <bool HAS_CSG>
-__global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, const RayRec* rays, double* out, Counters* counters) {
+__global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, double* out, Counters* counters) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool on = idx < n;
-    const RayRec* q = rays + (on ? idx : 0);
+    const uint32_t q = on ? idx : 0;
     Ray ray;
-    ray.o = mk(q->ox, q->oy, q->oz);
-    ray.d = mk(q->dx, q->dy, q->dz);
+    ray.o = mk(R.ox[q], R.oy[q], R.oz[q]);
+    ray.d = mk(R.dx[q], R.dy[q], R.dz[q]);
     uint32_t flops = 0, err = 0;
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
     int inside = 0;
@@ -1386,10 +1372,9 @@ struct rt_scene {
     bool has_csg = false, has_area = false;
     int device = 0;
     // workspace, grown on demand and kept between calls
-    NodeRec* recs = nullptr;
+    void* rec_slab = nullptr;           // one allocation carved into the arrays of R
+    Recs R{};
     size_t rec_cap = 0;
-    RayRec* queue[2] = {nullptr, nullptr};
-    size_t queue_cap = 0;
     Counters* counters = nullptr;
     Counters* counters_host = nullptr;  // pinned
     StatShard* stats = nullptr;
@@ -1400,9 +1385,6 @@ struct rt_scene {
     std::vector<hipEvent_t> launch_ev;  // start/stop pairs around every level kernel
     size_t chunk_pixels = (size_t)4 << 20;
     size_t recs_per_pixel = 24;
-    // shading inputs
-    TaskRec* tasks = nullptr;
-    size_t task_cap = 0;
     double* intensity = nullptr;
     size_t intensity_cap = 0;
     // rng order (area lights)
@@ -1419,22 +1401,23 @@ struct rt_scene {
 namespace {
 
 int ensure_workspace(rt_scene* s, size_t chunk_px, size_t n_first) {
-    size_t want_q = std::max<size_t>(2 * std::max(chunk_px, n_first), 1024);
     size_t want_r = std::max<size_t>(s->recs_per_pixel * std::max(chunk_px, n_first), 4096);
     if (want_r > 0x7FFFFFF0ull) want_r = 0x7FFFFFF0ull;
-    if (want_q > s->queue_cap) {
-        size_t cap = 0;
-        for (int k = 0; k < 2; k++) {
-            cap = s->queue_cap;
-            int rc = grow(&s->queue[k], &cap, want_q);
-            if (rc != RT_OK) return rc;
-        }
-        s->queue_cap = cap;
+    if (want_r > s->rec_cap) {
+        if (s->rec_slab) HIP_TRY(hipFree(s->rec_slab));
+        s->rec_slab = nullptr;
+        s->rec_cap = 0;
+        const size_t cap = (want_r + 63) & ~(size_t)63;  // every array starts 256-byte aligned
+        HIP_TRY(hipMalloc(&s->rec_slab, cap * REC_BYTES));
+        double* d = (double*)s->rec_slab;
+        double** dp[16] = {&s->R.ox, &s->R.oy, &s->R.oz, &s->R.dx, &s->R.dy, &s->R.dz, &s->R.px, &s->R.py,
+                           &s->R.pz, &s->R.nx, &s->R.ny, &s->R.nz, &s->R.reflectance, &s->R.r, &s->R.g, &s->R.b};
+        for (auto pp : dp) { *pp = d; d += cap; }
+        uint32_t* u = (uint32_t*)d;
+        uint32_t** up[4] = {&s->R.hit_pos, &s->R.child_refl, &s->R.child_refr, &s->R.order};
+        for (auto pp : up) { *pp = u; u += cap; }
+        s->rec_cap = cap;
     }
-    int rc = grow(&s->recs, &s->rec_cap, want_r);
-    if (rc != RT_OK) return rc;
-    rc = grow(&s->tasks, &s->task_cap, s->rec_cap);
-    if (rc != RT_OK) return rc;
     if (!s->counters) {
         HIP_TRY(hipMalloc((void**)&s->counters, sizeof(Counters)));
         HIP_TRY(hipMalloc((void**)&s->stats, STAT_SHARDS * sizeof(StatShard)));
@@ -1448,19 +1431,18 @@ struct RunTotals {
     uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0;
     uint64_t trace_launches = 0;
     uint32_t levels = 0;
-    double ms_trace = 0, ms_shadow = 0, ms_light = 0, ms_combine = 0;
+    double ms_trace = 0, ms_shadow = 0, ms_shade = 0;
 };
 
 struct FirstLevel {   // where the first level's rays come from
-    bool primary;     // true: pixels of a chunk; false: rays already in queue[0]
+    bool primary;     // true: pixels of a chunk; false: rays already in records [0, n)
     uint32_t n;       // number of first-level rays
     uint32_t width, rows;            // primary only
     const unsigned long long* seeds; // device: per global row (primary) or per ray; area lights only
 };
 
 // Run the levels for one batch of first-level rays, shade every shade point and fold the
-// records.  Returns RT_ERR_CAPACITY with *overflow set when a queue or the record buffer
-// was too small.
+// records.  Returns RT_ERR_CAPACITY with *overflow set when the record arrays were too small.
 template <bool HAS_CSG>
 int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
                uint8_t* out_rgb8, size_t out_offset, RunTotals& tot, bool* overflow) {
@@ -1469,7 +1451,6 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
     HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(Counters), 0));
     HIP_TRY(hipMemsetAsync(s->stats, 0, STAT_SHARDS * sizeof(StatShard), 0));
     uint32_t n = first.n, rec_base = 0;
-    int qi = 0;
     auto event = [&](size_t k) -> hipEvent_t {
         while (s->launch_ev.size() <= k) {
             hipEvent_t e = nullptr;
@@ -1481,11 +1462,7 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
     for (uint32_t level = 0;; level++) {
         LevelArgs A = base;
         A.n_rays = n;
-        A.in_rays = s->queue[qi];
-        A.out_rays = s->queue[qi ^ 1];
-        A.out_cap = (uint32_t)std::min<size_t>(s->queue_cap, 0xFFFFFFF0u);
-        A.recs = s->recs;
-        A.tasks = s->tasks;
+        A.R = s->R;
         A.rec_cap = (uint32_t)s->rec_cap;
         A.rec_base = rec_base;
         A.next_rec_base = rec_base + n;
@@ -1514,13 +1491,12 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
             return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed (csg list " + std::to_string(CSG_CAP) +
                                              ", container list " + std::to_string(CONT_CAP) + ")");
         if (error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
-        if (next > A.out_cap) { *overflow = true; return RT_ERR_CAPACITY; }
         rec_base += n;
+        if ((size_t)rec_base + next > s->rec_cap) { *overflow = true; return RT_ERR_CAPACITY; }
         if (next == 0 || level >= depth) break;
         // reset the append counter for the next level
         HIP_TRY(hipMemsetAsync(&s->counters->next_count, 0, sizeof(uint32_t), 0));
         n = next;
-        qi ^= 1;
     }
     const size_t n_levels = level_n.size();
     const uint32_t total_recs = rec_base;
@@ -1535,13 +1511,13 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
         const uint32_t n0 = level_n[0];
         const uint32_t width = first.primary ? first.width : 1, rows = first.primary ? first.rows : n0;
         for (int level = (int)n_levels - 1; level >= 0; level--)
-            hipLaunchKernelGGL(k_order_sizes, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->recs,
+            hipLaunchKernelGGL(k_order_sizes, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->R,
                                level_base[level], level_n[level]);
         int rc = grow(&s->pixel_base, &s->pixel_base_cap, (size_t)n0);
         if (rc == RT_OK) rc = grow(&s->row_total, &s->row_cap, (size_t)rows);
         if (rc == RT_OK) rc = grow(&s->row_base, &s->row_base_cap, (size_t)rows);
         if (rc != RT_OK) return rc;
-        hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->recs, width, rows, s->pixel_base,
+        hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->R, width, rows, s->pixel_base,
                            s->row_total);
         std::vector<uint32_t> totals(rows), bases(rows);
         HIP_TRY(hipMemcpy(totals.data(), s->row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1552,7 +1528,7 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
         rc = grow(&s->rng_states, &s->rng_cap, std::max<size_t>((size_t)acc, 1));
         if (rc != RT_OK) return rc;
         for (size_t level = 0; level < n_levels; level++)
-            hipLaunchKernelGGL(k_order_assign, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->recs,
+            hipLaunchKernelGGL(k_order_assign, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->R,
                                level_base[level], level_n[level], width, s->pixel_base, s->row_base, level == 0 ? 1 : 0);
         hipLaunchKernelGGL(k_rng_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->rng_states, s->row_base, s->row_total,
                            first.seeds, rows, first.primary ? base.chunk_row0 : 0u, first.primary ? base.part_block : 0u,
@@ -1561,14 +1537,15 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
         HIP_TRY(hipGetLastError());
     }
 
-    // shade every shade point of the chunk: shadow rays, then lighting
+    // shadow rays of every shade point of the chunk, then the colours level by level from the
+    // deepest; level 0 writes the outputs
     {
-        int rc = grow(&s->intensity, &s->intensity_cap, (size_t)total_recs * s->dev.n_lights);
+        int rc = grow(&s->intensity, &s->intensity_cap, s->rec_cap * s->dev.n_lights);
         if (rc != RT_OK) return rc;
         LevelArgs A = base;
         A.n_rays = total_recs;
-        A.recs = s->recs;
-        A.tasks = s->tasks;
+        A.R = s->R;
+        A.rec_cap = (uint32_t)s->rec_cap;
         A.intensity = s->intensity;
         A.rng_states = s->has_area ? s->rng_states : nullptr;
         A.counters = s->counters;
@@ -1577,20 +1554,15 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
         HIP_TRY(hipEventRecord(event(e), 0));
         hipLaunchKernelGGL((k_shadow<HAS_CSG>), dim3((total_recs + 255) / 256), dim3(256), 0, 0, s->dev, A);
         HIP_TRY(hipEventRecord(event(e + 1), 0));
-        hipLaunchKernelGGL(k_light, dim3((total_recs + 255) / 256), dim3(256), 0, 0, s->dev, A);
+        for (int level = (int)n_levels - 1; level >= 0; level--) {
+            A.n_rays = level_n[level];
+            A.rec_base = level_base[level];
+            if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
+            hipLaunchKernelGGL(k_shade, dim3((A.n_rays + 255) / 256), dim3(256), 0, 0, s->dev, A);
+        }
         HIP_TRY(hipEventRecord(event(e + 2), 0));
         HIP_TRY(hipGetLastError());
     }
-
-    // bottom-up fold; level 0 writes the outputs
-    for (int level = (int)n_levels - 1; level >= 0; level--) {
-        uint32_t ln = level_n[level];
-        bool emit = level == 0;
-        hipLaunchKernelGGL(k_combine, dim3((ln + 255) / 256), dim3(256), 0, 0, s->recs, level_base[level], ln,
-                           emit ? out_rgb : nullptr, emit ? out_rgb8 : nullptr, out_offset);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(event(2 * n_levels + 3), 0));
     HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
     std::vector<StatShard> shards(STAT_SHARDS);
     HIP_TRY(hipMemcpyAsync(shards.data(), s->stats, STAT_SHARDS * sizeof(StatShard), hipMemcpyDeviceToHost, 0));
@@ -1604,9 +1576,7 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
     HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e], s->launch_ev[e + 1]));
     tot.ms_shadow += ms;
     HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 1], s->launch_ev[e + 2]));
-    tot.ms_light += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 2], s->launch_ev[e + 3]));
-    tot.ms_combine += ms;
+    tot.ms_shade += ms;
     for (const StatShard& sh : shards) {
         tot.secondary += sh.secondary; tot.shadow += sh.shadow; tot.shade += sh.shade;
         tot.flop_trace += sh.flop_trace; tot.flop_shadow += sh.flop_shadow; tot.flop_light += sh.flop_light;
@@ -1639,13 +1609,12 @@ int upload_seeds(rt_scene* s, const uint64_t* seeds, size_t n) {
 }
 
 int upload_rays(rt_scene* s, uint32_t n, const double* rays) {
-    std::vector<RayRec> host(n);
-    for (uint32_t i = 0; i < n; i++) {
-        std::memset(&host[i], 0, sizeof(RayRec));
-        host[i].ox = rays[6 * (size_t)i + 0]; host[i].oy = rays[6 * (size_t)i + 1]; host[i].oz = rays[6 * (size_t)i + 2];
-        host[i].dx = rays[6 * (size_t)i + 3]; host[i].dy = rays[6 * (size_t)i + 4]; host[i].dz = rays[6 * (size_t)i + 5];
+    double* dst[6] = {s->R.ox, s->R.oy, s->R.oz, s->R.dx, s->R.dy, s->R.dz};
+    std::vector<double> host(n);
+    for (int c = 0; c < 6; c++) {
+        for (uint32_t i = 0; i < n; i++) host[i] = rays[6 * (size_t)i + c];
+        HIP_TRY(hipMemcpy(dst[c], host.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMemcpy(s->queue[0], host.data(), (size_t)n * sizeof(RayRec), hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -1829,14 +1798,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     for (void* p : s->allocations) (void)hipFree(p);
-    if (s->recs) (void)hipFree(s->recs);
-    for (auto& q : s->queue) if (q) (void)hipFree(q);
+    if (s->rec_slab) (void)hipFree(s->rec_slab);
     if (s->counters) (void)hipFree(s->counters);
     if (s->stats) (void)hipFree(s->stats);
     if (s->counters_host) (void)hipHostFree(s->counters_host);
     if (s->stage_rgb) (void)hipFree(s->stage_rgb);
     if (s->stage_rgb8) (void)hipFree(s->stage_rgb8);
-    if (s->tasks) (void)hipFree(s->tasks);
     if (s->intensity) (void)hipFree(s->intensity);
     if (s->rng_states) (void)hipFree(s->rng_states);
     if (s->pixel_base) (void)hipFree(s->pixel_base);
@@ -1914,7 +1881,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         if (rc == RT_ERR_CAPACITY && overflow) {
             if (nr <= 8) {
                 // cannot split further: grow the per-pixel record budget instead
-                if (s->recs_per_pixel >= 4096) return fail(RT_ERR_CAPACITY, "ray queues overflow even for an 8-row chunk");
+                if (s->recs_per_pixel >= 4096) return fail(RT_ERR_CAPACITY, "the record arrays overflow even for an 8-row chunk");
                 s->recs_per_pixel *= 4;
                 work.push_back({r0, nr});
                 continue;
@@ -1948,8 +1915,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->ms_total = ms;
         stats->ms_trace = tot.ms_trace;
         stats->ms_shadow = tot.ms_shadow;
-        stats->ms_light = tot.ms_light;
-        stats->ms_combine = tot.ms_combine;
+        stats->ms_shade = tot.ms_shade;
         stats->trace_launches = tot.trace_launches;
         stats->flop_trace = tot.flop_trace;
         stats->flop_shadow = tot.flop_shadow;
@@ -1992,7 +1958,7 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
         hipError_t e = hipMemcpy(out_rgb, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_ERR_HIP, hipGetErrorString(e));
     } else if (rc == RT_ERR_CAPACITY && overflow) {
-        fail(RT_ERR_CAPACITY, "ray queues overflow");
+        fail(RT_ERR_CAPACITY, "the record arrays overflow");
     }
     (void)hipFree(d_out);
     return rc;
@@ -2010,8 +1976,8 @@ int rt_probe(rt_scene* s, uint32_t n, const double* rays, double* out) {
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 32 * sizeof(double)));
     HIP_TRY(hipMemset(s->counters, 0, sizeof(Counters)));
     uint32_t blocks = (n + 255) / 256;
-    if (s->has_csg) hipLaunchKernelGGL((k_probe<true>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->queue[0], d_out, s->counters);
-    else hipLaunchKernelGGL((k_probe<false>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->queue[0], d_out, s->counters);
+    if (s->has_csg) hipLaunchKernelGGL((k_probe<true>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->R, d_out, s->counters);
+    else hipLaunchKernelGGL((k_probe<false>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->R, d_out, s->counters);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 32 * sizeof(double), hipMemcpyDeviceToHost);
     Counters c{};

@@ -28,7 +28,7 @@ def check(name, scale, depth, spheres=False, seed=0, threads=16):
     rel[ref == canvas.pixels] = 0
     exact = int((canvas.pixels == ref).all(axis=2).sum())
     print(f"{name} {g.width}x{g.height} depth {depth}: u8 mismatches {bad8}, f64 bit-exact px {exact}/{g.width*g.height}, max rel {rel.max():.3e}; "
-          f"gpu {st['ms_total']:.2f} ms (trace {st['ms_trace']:.2f} shadow {st['ms_shadow']:.2f} light {st['ms_light']:.2f} combine {st['ms_combine']:.2f}, first call {1e3*(t2-t1):.0f} ms wall, second {1e3*(t3-t2):.0f} ms), "
+          f"gpu {st['ms_total']:.2f} ms (trace {st['ms_trace']:.2f} shadow {st['ms_shadow']:.2f} shade {st['ms_shade']:.2f}, first call {1e3*(t2-t1):.0f} ms wall, second {1e3*(t3-t2):.0f} ms), "
           f"oracle {t4-t3:.2f}s x{threads}thr; rays p {st['primary_rays']} s {st['secondary_rays']} sh {st['shadow_rays']} levels {st['levels']} chunks {st['chunks']} "
           f"oracle counters {o.counters()}", flush=True)
     return bad8

@@ -11,7 +11,7 @@ import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line); r = d['roofline']; o = r['other_kernels']
-        print('frame %.1f ms  trace %.1f  shadow %.1f  light %.1f  combine %.1f  Mrays/s %.0f' % (d['ms_per_step'], r['kernel_ms_per_frame'], o['k_shadow']['ms_per_frame'], o['k_light']['ms_per_frame'], o['k_combine']['ms_per_frame'], d['value']))
+        print('frame %.1f ms  trace %.1f  shadow %.1f  shade %.1f  Mrays/s %.0f' % (d['ms_per_step'], r['kernel_ms_per_frame'], o['k_shadow']['ms_per_frame'], o['k_shade']['ms_per_frame'], d['value']))
 " >> gpurun_out/variants.log || { echo "FAILED $name" >> gpurun_out/variants.log; break; }
 done
 cp /tmp/librt_hip_orig.so raytracer_amd/librt_hip.so
