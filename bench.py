@@ -12,8 +12,9 @@ frame) / frame time.  Total work is fixed as N grows (strong scaling).
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints one JSON line.  At N=1 it also carries `roofline` (algorithmic
-f64 FLOP of the trace+shade kernel over its HIP-event time) and `cpu_baseline`
-(the CPU oracle timed on a bounded sample of rows of the same frame).
+f64 FLOP of the k_trace launches over their summed HIP-event time; the other
+kernels are listed beside it) and `cpu_baseline` (the CPU oracle timed on a
+bounded sample of rows of the same frame).
 """
 import argparse
 import json
@@ -48,7 +49,7 @@ def main():
     ap.add_argument("--scale", type=float, default=None, help="override the workload's --scale")
     ap.add_argument("--depth", type=int, default=None, help="override the workload's --depth")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame the CPU oracle renders for cpu_baseline")
+    ap.add_argument("--cpu-rows", type=int, default=768, help="rows of the frame the CPU oracle renders for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -156,9 +157,18 @@ def main():
             ms_k = stats["ms_trace"]
             launches = stats["trace_launches"]
             achieved = flop / (ms_k * 1e-3) / 1e12 if ms_k > 0 else 0.0
-            # algorithmic bytes: 64 B queue write + 64 B queue read per secondary ray, 64 B node record and 80 B
-            # shading record per ray, f64 + u8 frame buffer per pixel
-            alg_bytes = 128 * secondary + (64 + 80) * (primary + secondary) + 27 * primary
+            # algorithmic bytes of the record arrays (8-byte and 4-byte columns, one element per ray):
+            #   every ray: hit_pos written once, read by k_shadow and k_shade (12 B)
+            #   secondary ray: origin+direction written by the parent, read by k_trace (96 B);
+            #                  colour written by k_shade, read by the parent (48 B)
+            #   primary ray: direction written, read by k_shade (48 B); f64 + u8 frame buffers (27 B)
+            #   shade point: over_point+normal written (48 B), over_point read by k_shadow (24 B),
+            #                over_point+normal+direction read by k_shade (72 B, the direction's
+            #                write is counted above), child links written + read (16 B), one
+            #                intensity per light written + read (16 B)
+            n_lights = 1
+            shade = stats["shade_hits"]
+            alg_bytes = 12 * (primary + secondary) + 144 * secondary + 75 * primary + (48 + 24 + 72 + 16 + 16 * n_lights) * shade
             out["roofline"] = {
                 "bound": "valu_fp64",
                 "kernel": "k_trace (closest hit + n1/n2 + spawn; one launch per recursion level and chunk)",

@@ -49,8 +49,11 @@ constexpr int CSG_DEPTH = 6;       // nested csg levels
 constexpr int CONT_CAP = 32;       // intersections at or before a refractive hit
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
-#ifndef LEVEL_WAVES_PER_SIMD
-#define LEVEL_WAVES_PER_SIMD 2
+#ifndef TRACE_WAVES
+#define TRACE_WAVES 2     // occupancy the compiler must reach for k_trace (waves per SIMD)
+#endif
+#ifndef SHADOW_WAVES
+#define SHADOW_WAVES 2    // the same for k_shadow
 #endif
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256   // threads per k_trace block: one queue-append atomic per block
@@ -334,26 +337,24 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
 //    strict `<` against the running best keeps the reference's tie-break;
 //  * the container walk (intersection/mod.rs:62-94) needs every intersection
 //    that sorts before the hit.  Only an intersection below the running best can
-//    do so (an equal t that arrives later sorts after the hit), so the closest-hit
-//    walk records those (record = true) and the caller drops the ones that the
-//    final hit undercut.  A second walk (collect = true) gathers exactly the
-//    needed ones and is the fallback when the recorded list overflowed.
+//    do so (an equal t that arrives later sorts after the hit), so the walk
+//    records those and the caller drops the ones that the final hit undercut.
 struct Walk {
-    // closest hit so far
-    double t;
+    double t;              // closest hit so far
     uint32_t pos;          // unit position of the hit leaf's record, or NONE
-    uint32_t arrival, hit_arrival;
+    uint32_t arrival;      // intersections seen (the length of the reference's list)
     bool nan_seen;
-    // collect mode
-    double hit_t;
-    uint32_t want_arrival;
-    int n;
+    int n;                 // recorded candidates
     bool overflow;
 };
+DEV Walk walk_init() {
+    Walk w;
+    w.t = 0.0; w.pos = NONE; w.arrival = 0; w.nan_seen = false; w.n = 0; w.overflow = false;
+    return w;
+}
 
-// Where a walk keeps the (t, unit position, class) of intersections for the container walk:
-// entry k of this lane is at index k*stride.  The fast buffer is in LDS (lanes interleaved,
-// stride = block size), the overflow buffer is lane-private scratch (stride 1).
+// Where a walk keeps the (t, unit position, class) of its candidates: entry k of this lane is at
+// index k*stride.
 struct ContBuf {
     double* t;
     uint32_t* pos;
@@ -361,13 +362,28 @@ struct ContBuf {
     int stride, cap;
     DEV void put(int k, double tt, uint32_t p, uint32_t c) const { t[k * stride] = tt; pos[k * stride] = p; cls[k * stride] = c; }
 };
+// The first entries go to LDS (lanes interleaved, stride = block size), the rare rest to
+// lane-private scratch at the same index.
+struct RecordBuf {
+    ContBuf fast, big;
+    static constexpr bool enabled = true;
+    DEV int cap() const { return big.cap; }
+    DEV void put(int k, double tt, uint32_t p, uint32_t c) const {
+        if (k < fast.cap) fast.put(k, tt, p, c); else big.put(k, tt, p, c);
+    }
+};
+struct NoRecord {  // shadow rays only need the closest hit
+    static constexpr bool enabled = false;
+    DEV int cap() const { return 0; }
+    DEV void put(int, double, uint32_t, uint32_t) const {}
+};
 
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
-// object/csg/mod.rs:57-106).  `collect` is wave-uniform.
-template <bool HAS_CSG>
-DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect, bool record, Walk& w, ContBuf cb,
-                  uint32_t& flops, bool count, uint32_t& err) {
+// object/csg/mod.rs:57-106).  `record` is wave-uniform.
+template <bool HAS_CSG, class Buf>
+DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+                  bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
     const uint32_t n = S.n_units;
     const double* streamd = (const double*)S.stream;
@@ -382,18 +398,14 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
     // `cls` is the structural-equality class of the leaf at unit position p
     auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
         if (on) {
-            if (collect) {
-                if (tt < w.hit_t || (tt == w.hit_t && w.arrival < w.want_arrival)) {
-                    if (w.n < cb.cap) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
-                }
-            } else {
-                if (tt != tt) w.nan_seen = true;
-                const bool below = w.pos == NONE || tt < w.t;
+            if (tt != tt) w.nan_seen = true;
+            const bool below = w.pos == NONE || tt < w.t;
+            if constexpr (Buf::enabled) {
                 if (record && below) {
-                    if (w.n < cb.cap) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
+                    if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
                 }
-                if (tt > 0.0 && below) { w.t = tt; w.pos = p; w.hit_arrival = w.arrival; }
             }
+            if (tt > 0.0 && below) { w.t = tt; w.pos = p; }
             w.arrival++;
         }
     };
@@ -437,7 +449,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool collect,
                 }
                 if (cs_top == 0) {
                     for (int a = start; a < wr; a++)
-                        emit(true, ct[a], cl[a], (collect || record) ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
+                        emit(true, ct[a], cl[a], (Buf::enabled && record) ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
                     clen = start;
                 } else {
                     clen = wr;
@@ -614,7 +626,17 @@ struct Counters {  // per-level control words, read back by the host after every
 constexpr uint32_t STAT_SHARDS = 256;
 struct __attribute__((aligned(64))) StatShard {
     unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, pad[2];
+#ifdef RT_PHASE_TIMERS
+    unsigned long long phase[8];  // shader-clock ticks per k_trace phase, summed over waves
+#endif
 };
+// Diagnostic build (-DRT_PHASE_TIMERS): k_trace drains its memory counters at each PHASE mark and
+// adds the elapsed shader clock to StatShard::phase; rt_render prints the sums to stderr.
+#ifdef RT_PHASE_TIMERS
+#define PHASE(k) do { __builtin_amdgcn_s_waitcnt(0); phase_t[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE(k) do {} while (0)
+#endif
 
 struct LevelArgs {
     uint32_t n_rays;          // rays of this level (k_trace, k_shade) or records of the chunk (k_shadow)
@@ -762,6 +784,81 @@ DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, i
     r.n2 = n2_pos == NONE ? 1.0 : mat[(size_t)stream[(size_t)n2_pos * 16 + 1] * 8 + 6];
     return r;
 }
+// The same result for lists that fit the LDS buffer, computed in registers without sorting.  In the
+// reference's sorted walk an object is in `containers` iff it has appeared an odd number of times,
+// and the list's last element is the member that was pushed most recently, i.e. whose latest
+// appearance has the greatest (t, arrival) key.  So n1 comes from the odd-count object with the
+// greatest latest key among the entries before the hit; for n2 the hit object is toggled first.
+// An entry that equals the hit (same class, approx_eq t; intersection/mod.rs:64) ends the walk
+// early: it and everything after it in sorted order drop out.  `need` is false for lanes that only
+// keep the wave company.
+DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf cb, int n, bool need, double hit_t,
+                             uint32_t hit_pos, uint32_t hit_cls) {
+    constexpr int N = REC_CAP;
+    const int S = cb.stride;
+    double t[N];
+    uint32_t p[N], c[N];
+    bool v[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        t[k] = cb.t[k * S]; p[k] = cb.pos[k * S]; c[k] = cb.cls[k * S];
+        v[k] = need && k < n && t[k] < hit_t;
+    }
+    // early end of the walk (rare): the first entry in sorted order that equals the hit
+    bool m[N], any_m = false;
+#pragma unroll
+    for (int k = 0; k < N; k++) { m[k] = v[k] && c[k] == hit_cls && approx_eq(t[k], hit_t); any_m = any_m || m[k]; }
+    if (__ballot(any_m) != 0ull) {
+        bool have = false;
+        double st = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {  // ascending index: a strict `<` keeps the earliest arrival on ties
+            bool take = m[k] && (!have || t[k] < st);
+            if (take) { st = t[k]; have = true; }
+        }
+        bool passed = false;  // entries at or after the stop entry in (t, arrival) order
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            // the stop entry is the first index with t == st among m; later indices with t == st follow it
+            if (have && m[k] && t[k] == st) passed = true;
+            bool drop = have && (t[k] > st || (t[k] == st && passed));
+            v[k] = v[k] && !drop;
+        }
+    }
+    bool cand[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        bool odd = false, last = true;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            bool same = v[j] && c[j] == c[i];
+            odd = odd != same;
+            if (j != i) {
+                bool later = j > i ? t[j] >= t[i] : t[j] > t[i];
+                if (same && later) last = false;
+            }
+        }
+        cand[i] = v[i] && odd && last;
+    }
+    bool have1 = false, have2 = false, hit_present = false;
+    double t1 = 0.0, t2 = 0.0;
+    uint32_t n1_pos = NONE, n2_pos = NONE;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        bool is_hit_cls = c[i] == hit_cls;
+        if (cand[i] && (!have1 || t[i] >= t1)) { t1 = t[i]; n1_pos = p[i]; have1 = true; }
+        if (cand[i] && is_hit_cls) hit_present = true;
+        if (cand[i] && !is_hit_cls && (!have2 || t[i] >= t2)) { t2 = t[i]; n2_pos = p[i]; have2 = true; }
+    }
+    if (!hit_present) n2_pos = hit_pos;  // the hit object was pushed last
+    N1N2 r;
+    r.n1 = 1.0; r.n2 = 1.0;
+    if (need) {
+        if (n1_pos != NONE) r.n1 = mat[(size_t)stream[(size_t)n1_pos * 16 + 1] * 8 + 6];
+        if (n2_pos != NONE) r.n2 = mat[(size_t)stream[(size_t)n2_pos * 16 + 1] * 8 + 6];
+    }
+    return r;
+}
 // Lane-private scratch buffers make this one big; keep it out of line.
 __device__ __noinline__ N1N2 container_walk_scratch(const uint32_t* stream, const double* mat, double* ts, uint32_t* poss,
                                                     uint32_t* clss, int n, double hit_t, uint32_t hit_pos, uint32_t hit_cls) {
@@ -817,11 +914,16 @@ DEV uint32_t global_row(const LevelArgs& A, uint32_t local_row) {
 // colour_at for every ray of one level, minus the shading and the recursion
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
 template <bool PRIMARY, bool HAS_CSG>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SIMD) void k_trace(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t flops = 0, err = 0;
     bool on;
     uint32_t rec_idx;  // record of this ray (absolute)
+#ifdef RT_PHASE_TIMERS
+    unsigned long long phase_t[8];
+    phase_t[0] = __builtin_readcyclecounter();
+    for (int k = 1; k < 8; k++) phase_t[k] = phase_t[0];
+#endif
     Ray ray;
     if constexpr (PRIMARY) {
         // 8x8 pixel tile per wave; blocks are dealt to the 8 XCDs in contiguous screen bands
@@ -849,15 +951,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         ray.d = mk(A.R.dx[rec_idx], A.R.dy[rec_idx], A.R.dz[rec_idx]);
     }
 
+    PHASE(1);
     __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
-    const ContBuf fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
-    Walk w;
-    w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
-    w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
+    double big_t[CONT_CAP];
+    uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
+    RecordBuf buf;
+    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
+    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
+    Walk w = walk_init();
     // closest hit; scenes with a transparent material also record what may sort before it
     const bool record = (S.flags & 1u) != 0;
-    traverse<HAS_CSG>(S, ray, on, false, record, w, fast, flops, true, err);
+    traverse<HAS_CSG>(S, ray, on, record, w, buf, flops, true, err);
+    PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
     const double hit_t = w.t;
@@ -865,47 +971,29 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
     const uint32_t hit_cls = hit ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
     const double* mat_rec = S.mat + (hit ? (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 : 0);
     const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
-    // for refractive hits: the intersections that sort before the hit -> n1, n2
+    PHASE(3);
+    // for refractive hits: n1, n2 from the intersections that sort before the hit
     double n1 = 1.0, n2 = 1.0;
     const bool need_cont = hit && (!approx0(m_transparency) || m_transparency > 0.0);
-    const bool slow = need_cont && (w.overflow || !record);
-    if (__ballot(slow) != 0ull) {
-        // the recorded list overflowed: a collecting walk into the big lane-private buffer
-        double cont_t[CONT_CAP];
-        uint32_t cont_pos[CONT_CAP], cont_cls[CONT_CAP];
-        const ContBuf big = {cont_t, cont_pos, cont_cls, 1, CONT_CAP};
-        Walk w2 = w;
-        w2.hit_t = hit_t; w2.want_arrival = w.hit_arrival; w2.arrival = 0; w2.n = 0; w2.overflow = false;
-        uint32_t unused = 0;
-        traverse<HAS_CSG>(S, ray, slow, true, false, w2, big, unused, false, err);
-        if (slow) {
-            if (w2.overflow) err |= 2u;
-            N1N2 nn = container_walk_scratch(S.stream, S.mat, cont_t, cont_pos, cont_cls, w2.n, hit_t, hit_pos, hit_cls);
-            n1 = nn.n1; n2 = nn.n2;
+    if (__ballot(need_cont) != 0ull) {
+        const bool small = need_cont && w.n <= REC_CAP;
+        N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls);
+        if (need_cont && !small) {  // rare: continue in the lane-private buffer
+            if (w.overflow) err |= 2u;
+            for (int k = 0; k < REC_CAP; k++)
+                buf.big.put(k, buf.fast.t[k * TRACE_BLOCK], buf.fast.pos[k * TRACE_BLOCK], buf.fast.cls[k * TRACE_BLOCK]);
+            nn = container_walk_scratch(S.stream, S.mat, big_t, big_pos, big_cls, w.n, hit_t, hit_pos, hit_cls);
         }
+        if (need_cont) { n1 = nn.n1; n2 = nn.n2; }
     }
-    if (need_cont && !slow) {
-        N1N2 nn = container_walk(S.stream, S.mat, fast, w.n, hit_t, hit_pos, hit_cls);
-        n1 = nn.n1; n2 = nn.n2;
-#ifdef EXP_CONT2
-        nn = container_walk(S.stream, S.mat, fast, 0, hit_t, hit_pos, hit_cls);
-        if (nn.n1 == 77.0) n2 = 7.0;
-#endif
-    }
+    PHASE(4);
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
     if (hit) {
-#ifndef EXP_NO_GEOM
         HitGeom g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
         point = g.point; normal = g.normal;
-#ifdef EXP_GEOM2
-        g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
-        if (g.point.x != point.x) normal.x = 3.0;
-#endif
-#else
-        point = ray.o + ray.d * hit_t; normal = normalise(mk(ray.d.y, -ray.d.x + 0.1, 0.3));
-#endif
         flops += F_PREPARE;
     }
+    PHASE(5);
     const V3 eye = -ray.d;
     const V3 over = over_point_of(point, normal);
 
@@ -946,6 +1034,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         s_base = total ? atomicAdd(&A.counters->next_count, total) : 0u;
     }
     __syncthreads();
+    PHASE(6);
     if (n_refl + n_refr > 0) {
         uint32_t base = s_base;
         for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[k];
@@ -980,6 +1069,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_BLOCK / 256 * LEVEL_WAVES_PER_SI
         }
     }
 
+    PHASE(7);
+#ifdef RT_PHASE_TIMERS
+    if (lane == 0)
+        for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
+#endif
     // statistics: one atomic per wave and counter
     uint32_t s_shade = wave_sum_u32(hit ? 1u : 0u);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
@@ -1000,7 +1094,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // Lightable::intensity_at for every shade point and light (light/point.rs:27-38, light/area.rs:75-90):
 // one closest-hit shadow ray per light sample (World::is_shadowed, world.rs:109-126).
 template <bool HAS_CSG>
-__global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(256, SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     bool on = idx < A.n_rays;
@@ -1033,10 +1127,8 @@ __global__ __launch_bounds__(256, LEVEL_WAVES_PER_SIMD) void k_shadow(DevScene S
                 Ray sr;
                 sr.o = over;
                 sr.d = normalise(vec);
-                Walk w;
-                w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
-                w.hit_t = 0.0; w.want_arrival = 0; w.n = 0; w.overflow = false;
-                traverse<HAS_CSG>(S, sr, on, false, false, w, ContBuf{nullptr, nullptr, nullptr, 1, 0}, flops, true, err);
+                Walk w = walk_init();
+                traverse<HAS_CSG>(S, sr, on, false, w, NoRecord{}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
                 bool shadowed = false;
                 if (on && w.pos != NONE) {
@@ -1243,42 +1335,23 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     double n1 = 1.0, n2 = 1.0;
     __shared__ double s_rec_t[REC_CAP * 256];
     __shared__ uint32_t s_rec_pos[REC_CAP * 256], s_rec_cls[REC_CAP * 256];
-    const ContBuf fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, 256, REC_CAP};
-    Walk w;
+    double big_t[CONT_CAP];
+    uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
+    RecordBuf buf;
+    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, 256, REC_CAP};
+    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
+    Walk w = walk_init();
     bool hit = false, need = false;
     double hit_t = 0.0;
     uint32_t hit_pos = NONE, n_list = 0;
     double sh[4] = {0.0, 0.0, 0.0, 0.0};
     uint32_t n_l = S.n_lights < 4 ? S.n_lights : 4;
-    for (uint32_t job = 0; job < 2 + n_l; job++) {
+    for (uint32_t job = 0; job < 1 + n_l; job++) {
         Ray jr = ray;
         bool jon = on;
         double dist = 0.0;
-        if (job == 1) {
-            // n1 / n2 from the recorded candidates, or from a collecting walk where they overflowed
-            const uint32_t hit_cls = need ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
-            const bool slow = need && w.overflow;
-            if (__ballot(slow) != 0ull) {
-                double cont_t[CONT_CAP];
-                uint32_t cont_pos[CONT_CAP], cont_cls[CONT_CAP];
-                const ContBuf big = {cont_t, cont_pos, cont_cls, 1, CONT_CAP};
-                Walk w2 = w;
-                w2.hit_t = hit_t; w2.want_arrival = w.hit_arrival; w2.arrival = 0; w2.n = 0; w2.overflow = false;
-                traverse<HAS_CSG>(S, jr, slow, true, false, w2, big, flops, false, err);
-                if (slow) {
-                    if (w2.overflow) err |= 2u;
-                    N1N2 nn = container_walk_scratch(S.stream, S.mat, cont_t, cont_pos, cont_cls, w2.n, hit_t, hit_pos, hit_cls);
-                    n1 = nn.n1; n2 = nn.n2;
-                }
-            }
-            if (need && !slow) {
-                N1N2 nn = container_walk(S.stream, S.mat, fast, w.n, hit_t, hit_pos, hit_cls);
-                n1 = nn.n1; n2 = nn.n2;
-            }
-            continue;
-        }
-        if (job >= 2) {
-            uint32_t l = job - 2;
+        if (job >= 1) {
+            uint32_t l = job - 1;
             V3 lpos = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
             V3 over = over_point_of(point, normal);
             V3 vec = lpos - over;
@@ -1286,11 +1359,11 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
             jr.o = over;
             jr.d = normalise(vec);
             jon = hit;
+            w = walk_init();
+            traverse<HAS_CSG>(S, jr, jon, false, w, NoRecord{}, flops, false, err);
         } else {
-            w.n = 0; w.overflow = false;
+            traverse<HAS_CSG>(S, jr, jon, true, w, buf, flops, false, err);
         }
-        w.t = 0.0; w.pos = NONE; w.arrival = 0; w.hit_arrival = 0; w.nan_seen = false;
-        traverse<HAS_CSG>(S, jr, jon, false, job == 0, w, fast, flops, false, err);
         if (job == 0) {
             if (w.nan_seen && w.arrival >= 2) err |= 4u;
             hit = on && w.pos != NONE;
@@ -1301,11 +1374,23 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
             }
             double tr = hit ? S.mat[(size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 + 5] : 0.0;
             need = hit && (!approx0(tr) || tr > 0.0);
+            if (__ballot(need) != 0ull) {  // n1 / n2 from the recorded candidates
+                const uint32_t hit_cls = need ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
+                const bool small = need && w.n <= REC_CAP;
+                N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls);
+                if (need && !small) {
+                    if (w.overflow) err |= 2u;
+                    for (int k = 0; k < REC_CAP; k++)
+                        buf.big.put(k, buf.fast.t[k * 256], buf.fast.pos[k * 256], buf.fast.cls[k * 256]);
+                    nn = container_walk_scratch(S.stream, S.mat, big_t, big_pos, big_cls, w.n, hit_t, hit_pos, hit_cls);
+                }
+                if (need) { n1 = nn.n1; n2 = nn.n2; }
+            }
         } else {
             bool s = false;
             if (hit && w.pos != NONE) s = ((S.stream[(size_t)w.pos * 16] >> 8) & 1u) && w.t < dist;
             double v = s ? 1.0 : 0.0;
-            uint32_t l = job - 2;
+            uint32_t l = job - 1;
             if (l == 0) sh[0] = v; else if (l == 1) sh[1] = v; else if (l == 2) sh[2] = v; else sh[3] = v;
         }
     }
@@ -1577,6 +1662,14 @@ int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t de
     tot.ms_shadow += ms;
     HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 1], s->launch_ev[e + 2]));
     tot.ms_shade += ms;
+#ifdef RT_PHASE_TIMERS
+    {
+        unsigned long long ph[8] = {0};
+        for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
+        static const char* names[8] = {"", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
+        for (int k = 1; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
+    }
+#endif
     for (const StatShard& sh : shards) {
         tot.secondary += sh.secondary; tot.shadow += sh.shadow; tot.shade += sh.shade;
         tot.flop_trace += sh.flop_trace; tot.flop_shadow += sh.flop_shadow; tot.flop_light += sh.flop_light;
