@@ -166,7 +166,7 @@ def main():
             #                over_point+normal+direction read by k_shade (72 B, the direction's
             #                write is counted above), child links written + read (16 B), one
             #                intensity per light written + read (16 B)
-            n_lights = 1
+            n_lights = len(scene.desc()["light_kind"])
             shade = stats["shade_hits"]
             alg_bytes = 12 * (primary + secondary) + 144 * secondary + 75 * primary + (48 + 24 + 72 + 16 + 16 * n_lights) * shade
             out["roofline"] = {

@@ -31,6 +31,11 @@ ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error",
 )
+HOST_ABI_SYMBOLS = (
+    "rth_last_error", "rth_scene_from_file", "rth_scene_from_text", "rth_scene_spheres", "rth_scene_free",
+    "rth_scene_info", "rth_scene_desc", "rth_camera", "rth_camera_nudge_half_view", "rth_row_seeds", "rth_upload",
+    "rth_device_scene", "rth_render", "rth_colour_at", "rth_probe", "rth_write_ppm", "rth_write_png",
+)
 
 
 class RtError(RuntimeError):

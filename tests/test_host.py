@@ -32,6 +32,16 @@ def test_abi_exports_every_declared_symbol():
     assert isinstance(lib.rt_last_error(), bytes)
 
 
+def test_host_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rt_host.h")).read()
+    body = header[header.index("#ifndef RT_HOST_H"):]
+    declared = set(re.findall(r"\b(rth_[a-z0-9_]+)\s*\(", body))
+    assert declared == set(ra.HOST_ABI_SYMBOLS), declared ^ set(ra.HOST_ABI_SYMBOLS)
+    lib = ra.host_lib()
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
 def test_scene_create_rejects_bad_input_before_touching_the_gpu():
     lib = ra.hip_lib()
     out = C.c_void_p()
