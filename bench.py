@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=768, help="rows of the frame the CPU oracle renders for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1 or 2)")
+    ap.add_argument("--grid-blocks", type=int, default=None)
+    ap.add_argument("--chunk-pixels", type=int, default=None)
     args = ap.parse_args()
 
     import torch
@@ -84,6 +87,11 @@ def main():
         scene = ra.Scene.from_file(os.path.join(ROOT, scene_file), scale, args.seed)
     seeds = scene.row_seeds()
     scene.upload()
+    scene.set_option(ra.OPT_STREAMS, args.streams)
+    if args.grid_blocks:
+        scene.set_option(ra.OPT_GRID_BLOCKS, args.grid_blocks)
+    if args.chunk_pixels:
+        scene.set_option(ra.OPT_CHUNK_PIXELS, args.chunk_pixels)
     W, H = scene.width, scene.height
     part = multi.partition_for(rank, world) if world > 1 else None
     rows = len(ra.local_rows(H, part))

@@ -136,12 +136,15 @@ typedef struct rt_stats {
     uint64_t shade_hits;     /* shade_hit calls (src/world.rs:52)                  */
     uint32_t levels;         /* deepest recursion level that held rays, plus one   */
     uint32_t chunks;         /* row chunks the frame was rendered in               */
-    double ms_total;         /* device time of the whole call                      */
-    double ms_trace;         /* summed HIP-event durations of the k_trace launches
-                                (closest hit + n1/n2 + spawn, one per level)       */
-    double ms_shadow;        /* k_shadow launches (shadow rays, one per chunk)     */
-    double ms_shade;         /* k_shade launches (patterns + Phong + the sum with
-                                the spawned rays' colours, one per level)          */
+    double ms_total;         /* wall time of the whole call                        */
+    double ms_trace;         /* HIP-event time on the chunk's stream from the first
+                                to the last k_trace launch (closest hit + n1/n2 +
+                                spawn, one launch per level), summed over chunks;
+                                with two streams the chunks overlap, so the three
+                                sums can exceed ms_total                           */
+    double ms_shadow;        /* the same for k_shadow (shadow rays, one per chunk) */
+    double ms_shade;         /* the same for the k_shade launches (patterns + Phong
+                                + the sum with the spawned rays' colours)          */
     uint64_t trace_launches; /* number of k_trace launches                         */
     uint64_t flop_trace;     /* algorithmic f64 FLOP counted on the device in
                                 k_trace / k_shadow / k_shade: op-class counts x the
@@ -196,6 +199,19 @@ int rt_colour_at(rt_scene *scene, uint32_t n, const double *rays, uint32_t depth
  *  [29..31] unused.
  */
 int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
+
+/*
+ * Tuning knobs of a scene's renderer (no counterpart in the reference; the
+ * defaults suit a 288 GB MI355X).  Results do not depend on them.
+ *   RT_OPT_STREAMS         1 or 2: image-row chunks in flight at once (default 2)
+ *   RT_OPT_CHUNK_PIXELS    pixels per chunk (default 4 Mi); a chunk is whole rows,
+ *                          a multiple of 8 of them
+ *   RT_OPT_RECS_PER_PIXEL  ray records reserved per pixel of a chunk (default
+ *                          24); a chunk that needs more is split and retried
+ *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 2048)
+ */
+enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4 };
+int rt_set_option(rt_scene *scene, int option, uint64_t value);
 
 /* Limits of this build (per-ray list bounds). */
 uint32_t rt_max_csg_list(void);       /* intersections inside one outermost csg    */

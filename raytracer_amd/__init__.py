@@ -29,8 +29,9 @@ RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY, RT_ERR_NAN = -1
 # every symbol include/rt_api.h declares
 ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
-    "rt_max_csg_list", "rt_max_container_list", "rt_last_error",
+    "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
 )
+OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS = 1, 2, 3, 4
 HOST_ABI_SYMBOLS = (
     "rth_last_error", "rth_scene_from_file", "rth_scene_from_text", "rth_scene_spheres", "rth_scene_free",
     "rth_scene_info", "rth_scene_desc", "rth_camera", "rth_camera_nudge_half_view", "rth_row_seeds", "rth_upload",
@@ -104,6 +105,7 @@ def hip_lib():
                                 C.c_int, C.c_void_p]
         L.rt_colour_at.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         _hip = L
     return _hip
 
@@ -280,6 +282,12 @@ class Scene:
         if rc != RT_OK:
             raise RtError(rc, host_lib().rth_last_error().decode())
         return host_lib().rth_device_scene(self.h)
+
+    def set_option(self, option, value):
+        """rt_set_option on the uploaded scene (OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS)."""
+        rc = hip_lib().rt_set_option(self.upload(), option, value)
+        if rc != RT_OK:
+            raise RtError(rc, hip_lib().rt_last_error().decode())
 
     def render(self, depth=5, row_seeds=None, part=None, want_f64=True, want_u8=True):
         """Scene::render. Returns (Canvas, stats dict); with a partition the canvas holds only its rows."""

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -50,10 +51,13 @@ constexpr int CONT_CAP = 32;       // intersections at or before a refractive hi
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
 #ifndef TRACE_WAVES
-#define TRACE_WAVES 2     // occupancy the compiler must reach for k_trace (waves per SIMD)
+#define TRACE_WAVES 4     // occupancy the compiler must reach for k_trace (waves per SIMD; csg variants: 2)
 #endif
 #ifndef SHADOW_WAVES
-#define SHADOW_WAVES 2    // the same for k_shadow
+#define SHADOW_WAVES 5    // the same for k_shadow
+#endif
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 3     // and for k_shade
 #endif
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256   // threads per k_trace block: one queue-append atomic per block
@@ -63,6 +67,9 @@ constexpr int WAVE = 64;
 #endif
 
 #define DEV __device__ __forceinline__
+// At the top of a grid-stride loop: keeps the compiler from hoisting the body's loads out of the
+// loop, which would hold their registers across the whole body and cost a wave of occupancy.
+#define LOOP_FENCE() asm volatile("" ::: "memory")
 #define CADDR __attribute__((address_space(4)))
 
 // Loads through the constant address space: with a wave-uniform index the
@@ -617,9 +624,15 @@ struct Recs {
 };
 constexpr size_t REC_BYTES = 16 * sizeof(double) + 4 * sizeof(uint32_t);
 
-struct Counters {  // per-level control words, read back by the host after every k_trace launch
-    uint32_t next_count;  // rays appended to the next level
+struct Counters {
     uint32_t error;       // bit0 record arrays full, bit1 list overflow, bit2 NaN distance
+};
+// The levels of one chunk, kept on the device so that a level can be launched without the host
+// knowing how many rays the previous one spawned: level L traces records [base, base + n).
+struct LevelState { uint32_t n, base; };
+struct ChunkStatus {
+    uint32_t error, total_recs, levels, pad;
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light;  // this chunk's statistics
 };
 // Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
 // and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
@@ -639,7 +652,9 @@ struct __attribute__((aligned(64))) StatShard {
 #endif
 
 struct LevelArgs {
-    uint32_t n_rays;          // rays of this level (k_trace, k_shade) or records of the chunk (k_shadow)
+    LevelState* levels;       // per chunk; entry L+1 is filled while level L runs
+    uint32_t level;           // the level this launch works on (k_trace, k_shade)
+    uint32_t n_levels;        // levels[n_levels].base = records of the whole chunk (k_shadow)
     // primary mode: tile geometry of the chunk
     uint32_t width, chunk_row0, chunk_rows, tiles_x, n_tiles;
     uint32_t part_block, part_rank, part_world;  // row partition (global y of a local row)
@@ -648,8 +663,6 @@ struct LevelArgs {
     Recs R;                   // records of the whole chunk
     double* intensity;        // Lightable::intensity_at of light l for record i at [l * rec_cap + i]
     const Rng* rng_states;    // area lights only: one generator state per shade point of the chunk
-    uint32_t rec_base;        // first record of this level
-    uint32_t next_rec_base;   // first record of the next level
     uint32_t rec_cap;         // capacity of the record arrays
     uint32_t depth_remaining; // the reference's `depth` argument at this level
     // frame buffers (level 0 of k_shade), indexed from out_offset
@@ -906,17 +919,41 @@ DEV uint32_t global_row(const LevelArgs& A, uint32_t local_row) {
 }
 
 // ---------------------------------------------------------------- the three per-ray kernels
-// k_trace  (one launch per recursion level): closest hit, n1/n2, spawn, NodeRec + TaskRec
+// k_trace  (one launch per recursion level): closest hit, n1/n2, spawn, hit record
 // k_shadow (one launch per chunk, all levels at once): Lightable::intensity_at for every light
-// k_light  (one launch per chunk): pattern + Material::lighting; no tree walk, so the
-//          register-hungry pow() stays out of the walking kernels' allocation
+// k_shade  (one launch per level, deepest first): pattern + Material::lighting + the sum with the
+//          spawned rays' colours; no tree walk, so the register-hungry pow() stays out of the
+//          walking kernels' allocation
+// All three run as a fixed-size grid whose blocks stride over the work: how many rays a level
+// holds is only known on the device (LevelState).
 
 // colour_at for every ray of one level, minus the shading and the recursion
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
 template <bool PRIMARY, bool HAS_CSG>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t flops = 0, err = 0;
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    if (A.counters->error & 1u) return;  // an earlier level ran out of records: the chunk is retried
+    const LevelState lv = A.levels[A.level];
+    const uint32_t n_rays = lv.n, rec_base = lv.base, next_rec_base = lv.base + lv.n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.levels[A.level + 1].base = next_rec_base;
+    __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
+    __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
+    __shared__ uint32_t s_count[2][TRACE_BLOCK / 64];
+    __shared__ uint32_t s_base[2];
+    double big_t[CONT_CAP];
+    uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
+    RecordBuf buf;
+    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
+    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
+    const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
+    uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0;
+    // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
+    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
+                                     : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    uint32_t parity = 0;
+    for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x, parity ^= 1u) {
+    LOOP_FENCE();
     bool on;
     uint32_t rec_idx;  // record of this ray (absolute)
 #ifdef RT_PHASE_TIMERS
@@ -926,13 +963,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, 
 #endif
     Ray ray;
     if constexpr (PRIMARY) {
-        // 8x8 pixel tile per wave; blocks are dealt to the 8 XCDs in contiguous screen bands
-        // (blocks b and b+8 share an XCD and therefore an L2)
-        uint32_t nt = A.n_tiles;
-        uint32_t nb = gridDim.x, q = nb / 8, r = nb % 8, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
-        uint32_t vblock = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-        uint32_t tile = vblock * (TRACE_BLOCK / 64) + (threadIdx.x >> 6);
-        bool tile_ok = tile < nt;
+        // an 8x8 pixel tile per wave
+        uint32_t tile = step * (TRACE_BLOCK / 64) + wave_in_block;
+        bool tile_ok = tile < A.n_tiles;
         uint32_t tx = tile_ok ? tile % A.tiles_x : 0, ty = tile_ok ? tile / A.tiles_x : 0;
         uint32_t x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
         on = tile_ok && x < A.width && ly < A.chunk_rows;
@@ -944,24 +977,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, 
             A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
         }
     } else {
-        uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-        on = idx < A.n_rays;
-        rec_idx = A.rec_base + (on ? idx : 0);
+        uint32_t idx = step * TRACE_BLOCK + threadIdx.x;
+        on = idx < n_rays;
+        rec_idx = rec_base + (on ? idx : 0);
         ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
         ray.d = mk(A.R.dx[rec_idx], A.R.dy[rec_idx], A.R.dz[rec_idx]);
     }
 
     PHASE(1);
-    __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
-    __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
-    double big_t[CONT_CAP];
-    uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
-    RecordBuf buf;
-    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
-    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
     Walk w = walk_init();
-    // closest hit; scenes with a transparent material also record what may sort before it
-    const bool record = (S.flags & 1u) != 0;
+    // closest hit, recording what may sort before it
     traverse<HAS_CSG>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
@@ -1023,24 +1048,21 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, 
     unsigned long long b_refl = __ballot(spawn_refl), b_refr = __ballot(spawn_refr);
     uint32_t n_refl = __popcll(b_refl), n_refr = __popcll(b_refr);
     uint32_t child_refl = NONE, child_refr = NONE;
-    __shared__ uint32_t s_count[TRACE_BLOCK / 64];
-    __shared__ uint32_t s_base;
-    const uint32_t wave_in_block = threadIdx.x >> 6;
-    if (lane == 0) s_count[wave_in_block] = n_refl + n_refr;
+    if (lane == 0) s_count[parity][wave_in_block] = n_refl + n_refr;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t total = 0;
-        for (uint32_t k = 0; k < TRACE_BLOCK / 64; k++) total += s_count[k];
-        s_base = total ? atomicAdd(&A.counters->next_count, total) : 0u;
+        for (uint32_t k = 0; k < TRACE_BLOCK / 64; k++) total += s_count[parity][k];
+        s_base[parity] = total ? atomicAdd(&A.levels[A.level + 1].n, total) : 0u;
     }
     __syncthreads();
     PHASE(6);
     if (n_refl + n_refr > 0) {
-        uint32_t base = s_base;
-        for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[k];
+        uint32_t base = s_base[parity];
+        for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[parity][k];
         unsigned long long below = (1ull << lane) - 1ull;
         if (spawn_refl) {
-            uint32_t c = A.next_rec_base + base + __popcll(b_refl & below);
+            uint32_t c = next_rec_base + base + __popcll(b_refl & below);
             if (c < A.rec_cap) {
                 V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
                 A.R.ox[c] = over.x; A.R.oy[c] = over.y; A.R.oz[c] = over.z;
@@ -1049,7 +1071,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, 
             } else err |= 1u;
         }
         if (spawn_refr) {
-            uint32_t c = A.next_rec_base + base + n_refl + __popcll(b_refr & below);
+            uint32_t c = next_rec_base + base + n_refl + __popcll(b_refr & below);
             if (c < A.rec_cap) {
                 V3 o_ = under_point_of(point, normal);
                 A.R.ox[c] = o_.x; A.R.oy[c] = o_.y; A.R.oz[c] = o_.z;
@@ -1074,13 +1096,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, TRACE_WAVES) void k_trace(DevScene S, 
     if (lane == 0)
         for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
 #endif
+    n_spawned += n_refl + n_refr;  // wave-uniform
+    if (hit) n_shade++;
+    }  // steps
+
     // statistics: one atomic per wave and counter
-    uint32_t s_shade = wave_sum_u32(hit ? 1u : 0u);
+    uint32_t s_shade = wave_sum_u32(n_shade);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
-        if (n_refl + n_refr) atomicAdd(&st->secondary, (unsigned long long)(n_refl + n_refr));
+        if (n_spawned) atomicAdd(&st->secondary, (unsigned long long)n_spawned);
         if (s_shade) atomicAdd(&st->shade, (unsigned long long)s_shade);
         atomicAdd(&st->flop_trace, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
     }
@@ -1094,17 +1120,21 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // Lightable::intensity_at for every shade point and light (light/point.rs:27-38, light/area.rs:75-90):
 // one closest-hit shadow ray per light sample (World::is_shadowed, world.rs:109-126).
 template <bool HAS_CSG>
-__global__ __launch_bounds__(256, SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    bool on = idx < A.n_rays;
+    if (A.counters->error & 1u) return;
+    const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
+    uint32_t flops = 0, err = 0, n_shadow = 0;
+    for (uint32_t first = blockIdx.x * 256; first < total; first += gridDim.x * 256) {
+    LOOP_FENCE();
+    const uint32_t idx = first + threadIdx.x;
+    bool on = idx < total;
     const uint32_t rec_idx = on ? idx : 0;
     on = on && A.R.hit_pos[rec_idx] != NONE;
     const V3 over = on ? mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]) : mk(0.0, 0.0, 0.0);
     Rng rng;
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
-    uint32_t flops = 0, err = 0, n_shadow = 0;
     if (__ballot(on) != 0ull) {
         for (uint32_t l = 0; l < S.n_lights; l++) {
             const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
@@ -1145,6 +1175,7 @@ __global__ __launch_bounds__(256, SHADOW_WAVES) void k_shadow(DevScene S, LevelA
             if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
         }
     }
+    }  // records
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
@@ -1168,10 +1199,15 @@ DEV uint8_t to_u8(double c) {
 // (pattern/mod.rs:83-87), plus the colours of the spawned rays (world.rs:72-86,144,176).  No tree
 // walk here, so the register-hungry pow() stays out of the walking kernels' allocation.  Level 0
 // writes the frame buffers instead of the record.
-__global__ __launch_bounds__(256) void k_shade(DevScene S, LevelArgs A) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool on = idx < A.n_rays;
-    const uint32_t rec = A.rec_base + (on ? idx : 0);
+__global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArgs A) {
+    if (A.counters->error & 1u) return;
+    const LevelState lv = A.levels[A.level];
+    uint32_t flops_sum = 0;
+    for (uint32_t first = blockIdx.x * 256; first < lv.n; first += gridDim.x * 256) {
+    LOOP_FENCE();
+    const uint32_t idx = first + threadIdx.x;
+    const bool on = idx < lv.n;
+    const uint32_t rec = lv.base + (on ? idx : 0);
     const uint32_t hit_pos = on ? A.R.hit_pos[rec] : NONE;
     uint32_t flops = 0;
     V3 colour = mk(0.0, 0.0, 0.0);
@@ -1192,12 +1228,14 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, LevelArgs A) {
         V3 surface = mk(0.0, 0.0, 0.0);
         flops = F_PATTERN;
         for (uint32_t l = 0; l < S.n_lights; l++) {
-            const uint32_t usteps = S.light_meta[l * 4 + 1], vsteps = S.light_meta[l * 4 + 2];
+            // wave-uniform light data through the scalar cache
+            const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
             const uint32_t samples = usteps * vsteps;
-            const bool is_area = S.light_meta[l * 4 + 0] == RT_LIGHT_AREA;
-            const double* ld = S.light + (size_t)l * 12;
-            const V3 l0 = mk(ld[0], ld[1], ld[2]), uc = mk(ld[3], ld[4], ld[5]), vc = mk(ld[6], ld[7], ld[8]);
-            const V3 lint = is_area ? mk(ld[9], ld[10], ld[11]) : uc;
+            const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
+            const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+            const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
+            const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
+            const V3 lint = is_area ? mk(cld(S.light, l * 12 + 9), cld(S.light, l * 12 + 10), cld(S.light, l * 12 + 11)) : uc;
             const double intensity = A.intensity[(size_t)l * A.rec_cap + rec];
             if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
             V3 col = cmul(pat, lint);
@@ -1253,9 +1291,43 @@ __global__ __launch_bounds__(256) void k_shade(DevScene S, LevelArgs A) {
             A.R.r[rec] = colour.x; A.R.g[rec] = colour.y; A.R.b[rec] = colour.z;
         }
     }
+    flops_sum += flops;
+    }  // records
+    const uint32_t flops = flops_sum;
     uint32_t s_lo = wave_sum_u32(flops & 0xFFFFu), s_hi = wave_sum_u32(flops >> 16);
     if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
         atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
+}
+
+// Start of a chunk: level 0 holds n0 rays in records [0, n0); everything else is empty.
+__global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n0, Counters* counters) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_entries) { levels[i].n = i == 0 ? n0 : 0u; levels[i].base = 0u; }
+    if (i == 0) counters->error = 0u;
+}
+// End of a chunk: what the host needs to know about it, with the statistics lines added up and
+// cleared for the next chunk (a chunk that is retried must not count twice).  One block of
+// STAT_SHARDS threads.
+__global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* levels, uint32_t n_levels,
+                                                           const Counters* counters, StatShard* stats, ChunkStatus* out) {
+    __shared__ unsigned long long sums[6];
+    if (threadIdx.x < 6) sums[threadIdx.x] = 0ull;
+    __syncthreads();
+    StatShard* st = stats + threadIdx.x;
+    atomicAdd(&sums[0], st->secondary); atomicAdd(&sums[1], st->shadow); atomicAdd(&sums[2], st->shade);
+    atomicAdd(&sums[3], st->flop_trace); atomicAdd(&sums[4], st->flop_shadow); atomicAdd(&sums[5], st->flop_light);
+    st->secondary = 0; st->shadow = 0; st->shade = 0; st->flop_trace = 0; st->flop_shadow = 0; st->flop_light = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uint32_t used = 0;
+    for (uint32_t l = 0; l < n_levels; l++)
+        if (levels[l].n) used = l + 1;
+    out->error = counters->error;
+    out->total_recs = levels[n_levels].base;
+    out->levels = used;
+    out->pad = 0;
+    out->secondary = sums[0]; out->shadow = sums[1]; out->shade = sums[2];
+    out->flop_trace = sums[3]; out->flop_shadow = sums[4]; out->flop_light = sums[5];
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
@@ -1451,27 +1523,22 @@ int grow(T** buf, size_t* cap, size_t want) {
 
 }  // namespace
 
-struct rt_scene {
-    DevScene dev{};
-    std::vector<void*> allocations;
-    bool has_csg = false, has_area = false;
-    int device = 0;
-    // workspace, grown on demand and kept between calls
+// Everything one in-flight chunk needs: the record arrays, the level table and the stream its
+// kernels are queued on.  Two workspaces let two chunks overlap on the GPU.
+struct Workspace {
+    hipStream_t stream = nullptr;
     void* rec_slab = nullptr;           // one allocation carved into the arrays of R
     Recs R{};
     size_t rec_cap = 0;
-    Counters* counters = nullptr;
-    Counters* counters_host = nullptr;  // pinned
-    StatShard* stats = nullptr;
-    double* stage_rgb = nullptr;        // device staging for host outputs
-    uint8_t* stage_rgb8 = nullptr;
-    size_t stage_pixels = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> launch_ev;  // start/stop pairs around every level kernel
-    size_t chunk_pixels = (size_t)4 << 20;
-    size_t recs_per_pixel = 24;
     double* intensity = nullptr;
     size_t intensity_cap = 0;
+    LevelState* levels = nullptr;
+    size_t levels_cap = 0;
+    Counters* counters = nullptr;
+    StatShard* stats = nullptr;
+    ChunkStatus* status = nullptr;      // one entry per chunk queued on this workspace
+    size_t status_cap = 0;
+    std::vector<hipEvent_t> ev;         // four per queued chunk: start, traced, shadowed, shaded
     // rng order (area lights)
     Rng* rng_states = nullptr;
     size_t rng_cap = 0;
@@ -1479,37 +1546,75 @@ struct rt_scene {
     size_t pixel_base_cap = 0;
     uint32_t *row_total = nullptr, *row_base = nullptr;
     size_t row_cap = 0, row_base_cap = 0;
+};
+constexpr int MAX_STREAMS = 2;
+
+struct rt_scene {
+    DevScene dev{};
+    std::vector<void*> allocations;
+    bool has_csg = false, has_area = false;
+    int device = 0;
+    Workspace ws[MAX_STREAMS];
+    int n_streams = 2;
+    uint32_t grid_blocks = 2048;        // blocks of every level kernel (they stride over the rays)
+    double* stage_rgb = nullptr;        // device staging for host outputs
+    uint8_t* stage_rgb8 = nullptr;
+    size_t stage_pixels = 0;
+    size_t chunk_pixels = (size_t)4 << 20;
+    size_t recs_per_pixel = 24;
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
 };
 
 namespace {
 
-int ensure_workspace(rt_scene* s, size_t chunk_px, size_t n_first) {
+int ensure_workspace(rt_scene* s, Workspace& w, size_t chunk_px, size_t n_first, uint32_t depth, size_t n_chunks) {
+    if (!w.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void**)&w.counters, sizeof(Counters)));
+        HIP_TRY(hipMalloc((void**)&w.stats, STAT_SHARDS * sizeof(StatShard)));
+        HIP_TRY(hipMemsetAsync(w.stats, 0, STAT_SHARDS * sizeof(StatShard), w.stream));
+    }
     size_t want_r = std::max<size_t>(s->recs_per_pixel * std::max(chunk_px, n_first), 4096);
     if (want_r > 0x7FFFFFF0ull) want_r = 0x7FFFFFF0ull;
-    if (want_r > s->rec_cap) {
-        if (s->rec_slab) HIP_TRY(hipFree(s->rec_slab));
-        s->rec_slab = nullptr;
-        s->rec_cap = 0;
+    if (want_r > w.rec_cap) {
+        HIP_TRY(hipStreamSynchronize(w.stream));
+        if (w.rec_slab) HIP_TRY(hipFree(w.rec_slab));
+        w.rec_slab = nullptr;
+        w.rec_cap = 0;
         const size_t cap = (want_r + 63) & ~(size_t)63;  // every array starts 256-byte aligned
-        HIP_TRY(hipMalloc(&s->rec_slab, cap * REC_BYTES));
-        double* d = (double*)s->rec_slab;
-        double** dp[16] = {&s->R.ox, &s->R.oy, &s->R.oz, &s->R.dx, &s->R.dy, &s->R.dz, &s->R.px, &s->R.py,
-                           &s->R.pz, &s->R.nx, &s->R.ny, &s->R.nz, &s->R.reflectance, &s->R.r, &s->R.g, &s->R.b};
+        HIP_TRY(hipMalloc(&w.rec_slab, cap * REC_BYTES));
+        double* d = (double*)w.rec_slab;
+        double** dp[16] = {&w.R.ox, &w.R.oy, &w.R.oz, &w.R.dx, &w.R.dy, &w.R.dz, &w.R.px, &w.R.py,
+                           &w.R.pz, &w.R.nx, &w.R.ny, &w.R.nz, &w.R.reflectance, &w.R.r, &w.R.g, &w.R.b};
         for (auto pp : dp) { *pp = d; d += cap; }
         uint32_t* u = (uint32_t*)d;
-        uint32_t** up[4] = {&s->R.hit_pos, &s->R.child_refl, &s->R.child_refr, &s->R.order};
+        uint32_t** up[4] = {&w.R.hit_pos, &w.R.child_refl, &w.R.child_refr, &w.R.order};
         for (auto pp : up) { *pp = u; u += cap; }
-        s->rec_cap = cap;
+        w.rec_cap = cap;
     }
-    if (!s->counters) {
-        HIP_TRY(hipMalloc((void**)&s->counters, sizeof(Counters)));
-        HIP_TRY(hipMalloc((void**)&s->stats, STAT_SHARDS * sizeof(StatShard)));
-        HIP_TRY(hipHostMalloc((void**)&s->counters_host, sizeof(Counters)));
-        for (auto& e : s->ev) HIP_TRY(hipEventCreate(&e));
+    if (w.rec_cap * s->dev.n_lights > w.intensity_cap || (size_t)depth + 2 > w.levels_cap || n_chunks > w.status_cap)
+        HIP_TRY(hipStreamSynchronize(w.stream));
+    int rc = grow(&w.intensity, &w.intensity_cap, w.rec_cap * s->dev.n_lights);
+    if (rc == RT_OK) rc = grow(&w.levels, &w.levels_cap, (size_t)depth + 2);
+    if (rc == RT_OK) rc = grow(&w.status, &w.status_cap, std::max<size_t>(n_chunks, 16));
+    if (rc != RT_OK) return rc;
+    while (w.ev.size() < 4 * n_chunks) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        w.ev.push_back(e);
     }
     return RT_OK;
+}
+
+void free_workspace(Workspace& w) {
+    if (w.stream) (void)hipStreamSynchronize(w.stream);
+    void* bufs[] = {w.rec_slab, w.intensity, w.levels, w.counters, w.stats, w.status,
+                    w.rng_states, w.pixel_base, w.row_total, w.row_base};
+    for (void* p : bufs) if (p) (void)hipFree(p);
+    for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
+    if (w.stream) (void)hipStreamDestroy(w.stream);
+    w = Workspace{};
 }
 
 struct RunTotals {
@@ -1526,163 +1631,148 @@ struct FirstLevel {   // where the first level's rays come from
     const unsigned long long* seeds; // device: per global row (primary) or per ray; area lights only
 };
 
-// Run the levels for one batch of first-level rays, shade every shade point and fold the
-// records.  Returns RT_ERR_CAPACITY with *overflow set when the record arrays were too small.
+// Queue every kernel of one batch of first-level rays on the workspace's stream: the levels, the
+// shadow rays, then the colours from the deepest level up (level 0 writes the outputs).  Nothing
+// here waits for the GPU unless the scene has an area light (its rng order needs the level sizes
+// on the host).  `slot` selects the workspace's ChunkStatus entry and event quadruple.
 template <bool HAS_CSG>
-int run_levels(rt_scene* s, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
-               uint8_t* out_rgb8, size_t out_offset, RunTotals& tot, bool* overflow) {
-    *overflow = false;
-    std::vector<uint32_t> level_base, level_n;
-    HIP_TRY(hipMemsetAsync(s->counters, 0, sizeof(Counters), 0));
-    HIP_TRY(hipMemsetAsync(s->stats, 0, STAT_SHARDS * sizeof(StatShard), 0));
-    uint32_t n = first.n, rec_base = 0;
-    auto event = [&](size_t k) -> hipEvent_t {
-        while (s->launch_ev.size() <= k) {
-            hipEvent_t e = nullptr;
-            if (hipEventCreate(&e) != hipSuccess) return nullptr;
-            s->launch_ev.push_back(e);
-        }
-        return s->launch_ev[k];
-    };
-    for (uint32_t level = 0;; level++) {
-        LevelArgs A = base;
-        A.n_rays = n;
-        A.R = s->R;
-        A.rec_cap = (uint32_t)s->rec_cap;
-        A.rec_base = rec_base;
-        A.next_rec_base = rec_base + n;
-        A.depth_remaining = depth >= level ? depth - level : 0;
-        A.counters = s->counters;
-        A.stats = s->stats;
-        if ((size_t)rec_base + n > s->rec_cap) { *overflow = true; return RT_ERR_CAPACITY; }
-        level_base.push_back(rec_base);
-        level_n.push_back(n);
-        HIP_TRY(hipEventRecord(event(2 * level), 0));
+int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
+                uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
+    hipStream_t st = w.stream;
+    const uint32_t n_levels = depth + 1;
+    const dim3 grid(s->grid_blocks), block(256);
+    LevelArgs A = base;
+    A.levels = w.levels;
+    A.n_levels = n_levels;
+    A.R = w.R;
+    A.rec_cap = (uint32_t)w.rec_cap;
+    A.intensity = w.intensity;
+    A.rng_states = nullptr;
+    A.counters = w.counters;
+    A.stats = w.stats;
+    A.out_rgb = nullptr; A.out_rgb8 = nullptr; A.out_offset = 0;
+    hipLaunchKernelGGL(k_chunk_begin, dim3((n_levels + 1 + 255) / 256), dim3(256), 0, st, w.levels, n_levels + 1, first.n,
+                       w.counters);
+    HIP_TRY(hipEventRecord(w.ev[4 * slot + 0], st));
+    for (uint32_t level = 0; level < n_levels; level++) {
+        A.level = level;
+        A.depth_remaining = depth - level;
         if (first.primary && level == 0)
-            hipLaunchKernelGGL((k_trace<true, HAS_CSG>), dim3((A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)),
-                               dim3(TRACE_BLOCK), 0, 0, s->dev, A);
+            hipLaunchKernelGGL((k_trace<true, HAS_CSG>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
         else
-            hipLaunchKernelGGL((k_trace<false, HAS_CSG>), dim3((n + TRACE_BLOCK - 1) / TRACE_BLOCK), dim3(TRACE_BLOCK), 0, 0,
-                               s->dev, A);
-        tot.trace_launches++;
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(event(2 * level + 1), 0));
-        HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
-        HIP_TRY(hipStreamSynchronize(0));
-        uint32_t next = s->counters_host->next_count;
-        uint32_t error = s->counters_host->error;
-        if (error & 1u) { *overflow = true; return RT_ERR_CAPACITY; }
-        if (error & 2u)
-            return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed (csg list " + std::to_string(CSG_CAP) +
-                                             ", container list " + std::to_string(CONT_CAP) + ")");
-        if (error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
-        rec_base += n;
-        if ((size_t)rec_base + next > s->rec_cap) { *overflow = true; return RT_ERR_CAPACITY; }
-        if (next == 0 || level >= depth) break;
-        // reset the append counter for the next level
-        HIP_TRY(hipMemsetAsync(&s->counters->next_count, 0, sizeof(uint32_t), 0));
-        n = next;
+            hipLaunchKernelGGL((k_trace<false, HAS_CSG>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
     }
-    const size_t n_levels = level_n.size();
-    const uint32_t total_recs = rec_base;
-    float ms = 0;
-    for (size_t level = 0; level < n_levels; level++) {
-        HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[2 * level], s->launch_ev[2 * level + 1]));
-        tot.ms_trace += ms;
-    }
+    tot.trace_launches += n_levels;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(w.ev[4 * slot + 1], st));
 
     if (s->has_area) {
         // number the shade points in the reference's rng order and step the row generators to them
-        const uint32_t n0 = level_n[0];
-        const uint32_t width = first.primary ? first.width : 1, rows = first.primary ? first.rows : n0;
-        for (int level = (int)n_levels - 1; level >= 0; level--)
-            hipLaunchKernelGGL(k_order_sizes, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->R,
-                               level_base[level], level_n[level]);
-        int rc = grow(&s->pixel_base, &s->pixel_base_cap, (size_t)n0);
-        if (rc == RT_OK) rc = grow(&s->row_total, &s->row_cap, (size_t)rows);
-        if (rc == RT_OK) rc = grow(&s->row_base, &s->row_base_cap, (size_t)rows);
-        if (rc != RT_OK) return rc;
-        hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->R, width, rows, s->pixel_base,
-                           s->row_total);
-        std::vector<uint32_t> totals(rows), bases(rows);
-        HIP_TRY(hipMemcpy(totals.data(), s->row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        uint64_t acc = 0;
-        for (uint32_t r = 0; r < rows; r++) { bases[r] = (uint32_t)acc; acc += totals[r]; }
-        if (acc > 0xFFFFFFF0ull) return fail(RT_ERR_CAPACITY, "too many shade points in one chunk");
-        HIP_TRY(hipMemcpy(s->row_base, bases.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice));
-        rc = grow(&s->rng_states, &s->rng_cap, std::max<size_t>((size_t)acc, 1));
-        if (rc != RT_OK) return rc;
-        for (size_t level = 0; level < n_levels; level++)
-            hipLaunchKernelGGL(k_order_assign, dim3((level_n[level] + 255) / 256), dim3(256), 0, 0, s->R,
-                               level_base[level], level_n[level], width, s->pixel_base, s->row_base, level == 0 ? 1 : 0);
-        hipLaunchKernelGGL(k_rng_rows, dim3((rows + 63) / 64), dim3(64), 0, 0, s->rng_states, s->row_base, s->row_total,
-                           first.seeds, rows, first.primary ? base.chunk_row0 : 0u, first.primary ? base.part_block : 0u,
-                           first.primary ? base.part_rank : 0u, first.primary ? base.part_world : 1u,
-                           s->dev.draws_per_shade);
-        HIP_TRY(hipGetLastError());
+        std::vector<LevelState> lv(n_levels + 1);
+        HIP_TRY(hipMemcpyAsync(lv.data(), w.levels, lv.size() * sizeof(LevelState), hipMemcpyDeviceToHost, st));
+        Counters c{};
+        HIP_TRY(hipMemcpyAsync(&c, w.counters, sizeof c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (!(c.error & 1u)) {
+            const uint32_t n0 = lv[0].n;
+            const uint32_t width = first.primary ? first.width : 1, rows = first.primary ? first.rows : n0;
+            for (int level = (int)n_levels - 1; level >= 0; level--)
+                if (lv[level].n)
+                    hipLaunchKernelGGL(k_order_sizes, dim3((lv[level].n + 255) / 256), block, 0, st, w.R, lv[level].base,
+                                       lv[level].n);
+            int rc = grow(&w.pixel_base, &w.pixel_base_cap, (size_t)n0);
+            if (rc == RT_OK) rc = grow(&w.row_total, &w.row_cap, (size_t)rows);
+            if (rc == RT_OK) rc = grow(&w.row_base, &w.row_base_cap, (size_t)rows);
+            if (rc != RT_OK) return rc;
+            hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, st, w.R, width, rows, w.pixel_base,
+                               w.row_total);
+            std::vector<uint32_t> totals(rows), bases(rows);
+            HIP_TRY(hipMemcpyAsync(totals.data(), w.row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            uint64_t acc = 0;
+            for (uint32_t r = 0; r < rows; r++) { bases[r] = (uint32_t)acc; acc += totals[r]; }
+            if (acc > 0xFFFFFFF0ull) return fail(RT_ERR_CAPACITY, "too many shade points in one chunk");
+            HIP_TRY(hipMemcpyAsync(w.row_base, bases.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // `bases` goes out of scope
+            rc = grow(&w.rng_states, &w.rng_cap, std::max<size_t>((size_t)acc, 1));
+            if (rc != RT_OK) return rc;
+            for (uint32_t level = 0; level < n_levels; level++)
+                if (lv[level].n)
+                    hipLaunchKernelGGL(k_order_assign, dim3((lv[level].n + 255) / 256), block, 0, st, w.R, lv[level].base,
+                                       lv[level].n, width, w.pixel_base, w.row_base, level == 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_rng_rows, dim3((rows + 63) / 64), dim3(64), 0, st, w.rng_states, w.row_base, w.row_total,
+                               first.seeds, rows, first.primary ? base.chunk_row0 : 0u,
+                               first.primary ? base.part_block : 0u, first.primary ? base.part_rank : 0u,
+                               first.primary ? base.part_world : 1u, s->dev.draws_per_shade);
+            HIP_TRY(hipGetLastError());
+            A.rng_states = w.rng_states;
+        }
     }
 
-    // shadow rays of every shade point of the chunk, then the colours level by level from the
-    // deepest; level 0 writes the outputs
-    {
-        int rc = grow(&s->intensity, &s->intensity_cap, s->rec_cap * s->dev.n_lights);
-        if (rc != RT_OK) return rc;
-        LevelArgs A = base;
-        A.n_rays = total_recs;
-        A.R = s->R;
-        A.rec_cap = (uint32_t)s->rec_cap;
-        A.intensity = s->intensity;
-        A.rng_states = s->has_area ? s->rng_states : nullptr;
-        A.counters = s->counters;
-        A.stats = s->stats;
-        const size_t e = 2 * n_levels;
-        HIP_TRY(hipEventRecord(event(e), 0));
-        hipLaunchKernelGGL((k_shadow<HAS_CSG>), dim3((total_recs + 255) / 256), dim3(256), 0, 0, s->dev, A);
-        HIP_TRY(hipEventRecord(event(e + 1), 0));
-        for (int level = (int)n_levels - 1; level >= 0; level--) {
-            A.n_rays = level_n[level];
-            A.rec_base = level_base[level];
-            if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
-            hipLaunchKernelGGL(k_shade, dim3((A.n_rays + 255) / 256), dim3(256), 0, 0, s->dev, A);
-        }
-        HIP_TRY(hipEventRecord(event(e + 2), 0));
-        HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_shadow<HAS_CSG>), grid, block, 0, st, s->dev, A);
+    HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
+    for (int level = (int)n_levels - 1; level >= 0; level--) {
+        A.level = (uint32_t)level;
+        if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
+        hipLaunchKernelGGL(k_shade, grid, block, 0, st, s->dev, A);
     }
-    HIP_TRY(hipMemcpyAsync(s->counters_host, s->counters, sizeof(Counters), hipMemcpyDeviceToHost, 0));
-    std::vector<StatShard> shards(STAT_SHARDS);
-    HIP_TRY(hipMemcpyAsync(shards.data(), s->stats, STAT_SHARDS * sizeof(StatShard), hipMemcpyDeviceToHost, 0));
-    HIP_TRY(hipStreamSynchronize(0));
-    {
-        uint32_t error = s->counters_host->error;
-        if (error & 2u) return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed");
-        if (error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
-    }
-    const size_t e = 2 * n_levels;
-    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e], s->launch_ev[e + 1]));
-    tot.ms_shadow += ms;
-    HIP_TRY(hipEventElapsedTime(&ms, s->launch_ev[e + 1], s->launch_ev[e + 2]));
-    tot.ms_shade += ms;
-#ifdef RT_PHASE_TIMERS
-    {
-        unsigned long long ph[8] = {0};
-        for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
-        static const char* names[8] = {"", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
-        for (int k = 1; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
-    }
-#endif
-    for (const StatShard& sh : shards) {
-        tot.secondary += sh.secondary; tot.shadow += sh.shadow; tot.shade += sh.shade;
-        tot.flop_trace += sh.flop_trace; tot.flop_shadow += sh.flop_shadow; tot.flop_light += sh.flop_light;
-    }
-    tot.levels = std::max<uint32_t>(tot.levels, (uint32_t)n_levels);
+    HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
+    hipLaunchKernelGGL(k_chunk_end, dim3(1), dim3(STAT_SHARDS), 0, st, w.levels, n_levels, w.counters, w.stats,
+                       w.status + slot);
+    HIP_TRY(hipGetLastError());
     return RT_OK;
 }
 
-int run_levels_dispatch(rt_scene* s, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
-                        double* out_rgb, uint8_t* out_rgb8, size_t out_offset, RunTotals& tot, bool* overflow) {
-    if (s->has_csg) return run_levels<true>(s, base, first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
-    return run_levels<false>(s, base, first, depth, out_rgb, out_rgb8, out_offset, tot, overflow);
+int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
+                         double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
+    if (s->has_csg) return queue_chunk<true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    return queue_chunk<false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
 }
+
+// Wait for a workspace's stream and fetch the status of its first `n_slots` chunks.
+int collect(Workspace& w, size_t n_slots, std::vector<ChunkStatus>& out, RunTotals& tot) {
+    out.assign(n_slots, ChunkStatus{});
+    if (n_slots == 0) return RT_OK;
+    HIP_TRY(hipMemcpyAsync(out.data(), w.status, n_slots * sizeof(ChunkStatus), hipMemcpyDeviceToHost, w.stream));
+    HIP_TRY(hipStreamSynchronize(w.stream));
+    float ms = 0;
+    for (size_t k = 0; k < n_slots; k++) {
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[4 * k + 0], w.ev[4 * k + 1]));
+        tot.ms_trace += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[4 * k + 1], w.ev[4 * k + 2]));
+        tot.ms_shadow += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, w.ev[4 * k + 2], w.ev[4 * k + 3]));
+        tot.ms_shade += ms;
+    }
+    return RT_OK;
+}
+
+void add_stats(RunTotals& tot, const ChunkStatus& c) {
+    tot.secondary += c.secondary; tot.shadow += c.shadow; tot.shade += c.shade;
+    tot.flop_trace += c.flop_trace; tot.flop_shadow += c.flop_shadow; tot.flop_light += c.flop_light;
+    tot.levels = std::max(tot.levels, c.levels);
+}
+
+int check_status(const ChunkStatus& c) {
+    if (c.error & 2u)
+        return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed (csg list " + std::to_string(CSG_CAP) +
+                                         ", container list " + std::to_string(CONT_CAP) + ")");
+    if (c.error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
+    return RT_OK;
+}
+
+#ifdef RT_PHASE_TIMERS
+// Diagnostic build: print and clear the per-phase shader-clock sums of k_trace.
+void print_phases(Workspace& w) {
+    std::vector<StatShard> shards(STAT_SHARDS);
+    if (hipMemcpy(shards.data(), w.stats, STAT_SHARDS * sizeof(StatShard), hipMemcpyDeviceToHost) != hipSuccess) return;
+    (void)hipMemset(w.stats, 0, STAT_SHARDS * sizeof(StatShard));
+    unsigned long long ph[8] = {0};
+    for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
+    static const char* names[8] = {"", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
+    for (int k = 1; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
+}
+#endif
 
 uint32_t local_rows(const rt_camera* cam, const rt_partition* p) {
     if (!p || p->world <= 1) return cam->height;
@@ -1701,8 +1791,8 @@ int upload_seeds(rt_scene* s, const uint64_t* seeds, size_t n) {
     return RT_OK;
 }
 
-int upload_rays(rt_scene* s, uint32_t n, const double* rays) {
-    double* dst[6] = {s->R.ox, s->R.oy, s->R.oz, s->R.dx, s->R.dy, s->R.dz};
+int upload_rays(Workspace& w, uint32_t n, const double* rays) {
+    double* dst[6] = {w.R.ox, w.R.oy, w.R.oz, w.R.dx, w.R.dy, w.R.dz};
     std::vector<double> host(n);
     for (int c = 0; c < 6; c++) {
         for (uint32_t i = 0; i < n; i++) host[i] = rays[6 * (size_t)i + c];
@@ -1890,22 +1980,42 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
 
 void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
+    for (auto& w : s->ws) free_workspace(w);
     for (void* p : s->allocations) (void)hipFree(p);
-    if (s->rec_slab) (void)hipFree(s->rec_slab);
-    if (s->counters) (void)hipFree(s->counters);
-    if (s->stats) (void)hipFree(s->stats);
-    if (s->counters_host) (void)hipHostFree(s->counters_host);
     if (s->stage_rgb) (void)hipFree(s->stage_rgb);
     if (s->stage_rgb8) (void)hipFree(s->stage_rgb8);
-    if (s->intensity) (void)hipFree(s->intensity);
-    if (s->rng_states) (void)hipFree(s->rng_states);
-    if (s->pixel_base) (void)hipFree(s->pixel_base);
-    if (s->row_total) (void)hipFree(s->row_total);
-    if (s->row_base) (void)hipFree(s->row_base);
     if (s->seeds) (void)hipFree(s->seeds);
-    for (auto& e : s->ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : s->launch_ev) if (e) (void)hipEventDestroy(e);
     delete s;
+}
+
+int rt_set_option(rt_scene* s, int option, uint64_t value) {
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    switch (option) {
+        case RT_OPT_STREAMS:
+            if (value < 1 || value > MAX_STREAMS) return fail(RT_ERR_INVALID, "streams must be 1 or 2");
+            s->n_streams = (int)value;
+            return RT_OK;
+        case RT_OPT_CHUNK_PIXELS:
+            if (value < 64) return fail(RT_ERR_INVALID, "chunk_pixels must be at least 64");
+            s->chunk_pixels = (size_t)value;
+            return RT_OK;
+        case RT_OPT_RECS_PER_PIXEL:
+            if (value < 1 || value > 4096) return fail(RT_ERR_INVALID, "recs_per_pixel must be in 1..4096");
+            s->recs_per_pixel = (size_t)value;
+            for (auto& w : s->ws) {  // shrink on the next call
+                if (w.stream) (void)hipStreamSynchronize(w.stream);
+                if (w.rec_slab) (void)hipFree(w.rec_slab);
+                w.rec_slab = nullptr; w.rec_cap = 0;
+                if (w.intensity) (void)hipFree(w.intensity);
+                w.intensity = nullptr; w.intensity_cap = 0;
+            }
+            return RT_OK;
+        case RT_OPT_GRID_BLOCKS:
+            if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 1..65536");
+            s->grid_blocks = (uint32_t)value;
+            return RT_OK;
+    }
+    return fail(RT_ERR_INVALID, "unknown option");
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t* row_seeds, const rt_partition* part,
@@ -1927,10 +2037,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     const uint32_t rows = local_rows(cam, &p);
     RunTotals tot;
     uint32_t chunks = 0;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, 0));
+    HIP_TRY(hipDeviceSynchronize());  // the outputs may have work queued on them by the caller
+    const auto t_start = std::chrono::steady_clock::now();
 
     // device outputs (stage when the caller's buffers are host memory)
     double* d_rgb = out_rgb;
@@ -1950,53 +2058,77 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         d_rgb8 = out_rgb8 ? s->stage_rgb8 : nullptr;
     }
 
-    // row chunks: multiples of 8 rows, at most chunk_pixels pixels
+    // row chunks: multiples of 8 rows, at most chunk_pixels pixels.  Each pass queues every
+    // pending chunk (alternating over the workspaces so two chunks overlap on the GPU), then
+    // waits; chunks whose rays did not fit their record arrays are split and go round again.
     uint32_t chunk_rows = (uint32_t)std::max<size_t>(8, (s->chunk_pixels / W) & ~(size_t)7);
-    std::vector<std::pair<uint32_t, uint32_t>> work;  // (row0, rows)
-    for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) work.push_back({r0, std::min(chunk_rows, rows - r0)});
-    std::reverse(work.begin(), work.end());
-    while (!work.empty()) {
-        auto [r0, nr] = work.back();
-        work.pop_back();
-        size_t px = (size_t)nr * W;
-        int rc = ensure_workspace(s, px, 0);
-        if (rc != RT_OK) return rc;
-        LevelArgs A{};
-        A.width = W; A.chunk_row0 = r0; A.chunk_rows = nr;
-        A.tiles_x = (W + 7) / 8;
-        A.n_tiles = A.tiles_x * ((nr + 7) / 8);
-        A.part_block = p.block_rows; A.part_rank = p.rank; A.part_world = p.world;
-        std::memcpy(A.cam_inv, cam->inv, sizeof A.cam_inv);
-        A.half_width = cam->half_width; A.half_height = cam->half_height; A.pixel_size = cam->pixel_size;
-        FirstLevel first{true, (uint32_t)px, W, nr, s->seeds};
-        bool overflow = false;
-        rc = run_levels_dispatch(s, A, first, depth, d_rgb, d_rgb8, (size_t)r0 * W, tot, &overflow);
-        if (rc == RT_ERR_CAPACITY && overflow) {
-            if (nr <= 8) {
-                // cannot split further: grow the per-pixel record budget instead
-                if (s->recs_per_pixel >= 4096) return fail(RT_ERR_CAPACITY, "the record arrays overflow even for an 8-row chunk");
-                s->recs_per_pixel *= 4;
-                work.push_back({r0, nr});
-                continue;
-            }
-            uint32_t half = ((nr / 2) + 7) & ~7u;
-            work.push_back({r0 + half, nr - half});
-            work.push_back({r0, half});
-            continue;
+    struct Job { uint32_t r0, nr; };
+    std::vector<Job> pending;
+    for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0)});
+    const int n_ws = std::max(1, std::min(s->n_streams, MAX_STREAMS));
+    while (!pending.empty()) {
+        std::vector<Job> queued[MAX_STREAMS];
+        size_t max_px = 0;
+        for (const Job& j : pending) max_px = std::max(max_px, (size_t)j.nr * W);
+        for (int k = 0; k < n_ws; k++) {
+            size_t share = (pending.size() + n_ws - 1) / n_ws;
+            int rc = ensure_workspace(s, s->ws[k], max_px, 0, depth, share);
+            if (rc != RT_OK) return rc;
         }
-        if (rc != RT_OK) return rc;
-        chunks++;
+        for (size_t i = 0; i < pending.size(); i++) {
+            const Job& j = pending[i];
+            const int k = (int)(i % n_ws);
+            LevelArgs A{};
+            A.width = W; A.chunk_row0 = j.r0; A.chunk_rows = j.nr;
+            A.tiles_x = (W + 7) / 8;
+            A.n_tiles = A.tiles_x * ((j.nr + 7) / 8);
+            A.part_block = p.block_rows; A.part_rank = p.rank; A.part_world = p.world;
+            std::memcpy(A.cam_inv, cam->inv, sizeof A.cam_inv);
+            A.half_width = cam->half_width; A.half_height = cam->half_height; A.pixel_size = cam->pixel_size;
+            FirstLevel first{true, (uint32_t)((size_t)j.nr * W), W, j.nr, s->seeds};
+            int rc = queue_chunk_dispatch(s, s->ws[k], A, first, depth, d_rgb, d_rgb8, (size_t)j.r0 * W,
+                                          queued[k].size(), tot);
+            if (rc != RT_OK) return rc;
+            queued[k].push_back(j);
+        }
+        pending.clear();
+        bool grow_budget = false;
+        for (int k = 0; k < n_ws; k++) {
+            std::vector<ChunkStatus> st;
+            int rc = collect(s->ws[k], queued[k].size(), st, tot);
+            if (rc != RT_OK) return rc;
+            for (size_t i = 0; i < st.size(); i++) {
+                const Job& j = queued[k][i];
+                if (st[i].error & 1u) {
+                    if (j.nr <= 8) {
+                        grow_budget = true;  // cannot split further: grow the per-pixel record budget
+                        pending.push_back(j);
+                    } else {
+                        uint32_t half = ((j.nr / 2) + 7) & ~7u;
+                        pending.push_back({j.r0, half});
+                        pending.push_back({j.r0 + half, j.nr - half});
+                    }
+                    continue;
+                }
+                rc = check_status(st[i]);
+                if (rc != RT_OK) return rc;
+                add_stats(tot, st[i]);
+                chunks++;
+            }
+        }
+        if (grow_budget) {
+            if (s->recs_per_pixel >= 4096) return fail(RT_ERR_CAPACITY, "the record arrays overflow even for an 8-row chunk");
+            s->recs_per_pixel *= 4;
+        }
     }
+#ifdef RT_PHASE_TIMERS
+    for (int k = 0; k < n_ws; k++) print_phases(s->ws[k]);
+#endif
     if (!out_on_device) {
         if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, d_rgb, total_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
         if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, d_rgb8, total_px * 3, hipMemcpyDeviceToHost));
     }
-    HIP_TRY(hipEventRecord(e1, 0));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->primary_rays = total_px;
@@ -2021,37 +2153,38 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
     if (!s || (n && (!rays || !out_rgb))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    int rc = ensure_workspace(s, 0, n);
-    if (rc != RT_OK) return rc;
     if (s->has_area) {
-        rc = upload_seeds(s, seeds, n);  // a missing list seeds every ray's generator with 0
+        int rc = upload_seeds(s, seeds, n);  // a missing list seeds every ray's generator with 0
         if (rc != RT_OK) return rc;
     }
-    rc = upload_rays(s, n, rays);
-    if (rc != RT_OK) return rc;
+    Workspace& w = s->ws[0];
     double* d_out = nullptr;
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(double)));
     LevelArgs A{};
     A.part_world = 1;
     RunTotals tot;
-    bool overflow = false;
+    int rc = RT_OK;
     for (;;) {
+        rc = ensure_workspace(s, w, 0, n, depth, 1);
+        if (rc == RT_OK) rc = upload_rays(w, n, rays);
+        if (rc != RT_OK) break;
         FirstLevel first{false, n, 1, n, s->seeds};
-        rc = run_levels_dispatch(s, A, first, depth, d_out, nullptr, 0, tot, &overflow);
-        if (rc == RT_ERR_CAPACITY && overflow && s->recs_per_pixel < 4096) {
+        rc = queue_chunk_dispatch(s, w, A, first, depth, d_out, nullptr, 0, 0, tot);
+        if (rc != RT_OK) break;
+        std::vector<ChunkStatus> st;
+        rc = collect(w, 1, st, tot);
+        if (rc != RT_OK) break;
+        if (st[0].error & 1u) {
+            if (s->recs_per_pixel >= 4096) { rc = fail(RT_ERR_CAPACITY, "the record arrays overflow"); break; }
             s->recs_per_pixel *= 4;
-            int rc2 = ensure_workspace(s, 0, n);
-            if (rc2 == RT_OK) rc2 = upload_rays(s, n, rays);
-            if (rc2 != RT_OK) { (void)hipFree(d_out); return rc2; }
             continue;
         }
+        rc = check_status(st[0]);
         break;
     }
     if (rc == RT_OK) {
         hipError_t e = hipMemcpy(out_rgb, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(RT_ERR_HIP, hipGetErrorString(e));
-    } else if (rc == RT_ERR_CAPACITY && overflow) {
-        fail(RT_ERR_CAPACITY, "the record arrays overflow");
     }
     (void)hipFree(d_out);
     return rc;
@@ -2061,20 +2194,22 @@ int rt_probe(rt_scene* s, uint32_t n, const double* rays, double* out) {
     if (!s || (n && (!rays || !out))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
-    int rc = ensure_workspace(s, 0, n);
+    Workspace& w = s->ws[0];
+    int rc = ensure_workspace(s, w, 0, n, 0, 1);
     if (rc != RT_OK) return rc;
-    rc = upload_rays(s, n, rays);
+    rc = upload_rays(w, n, rays);
     if (rc != RT_OK) return rc;
     double* d_out = nullptr;
     HIP_TRY(hipMalloc((void**)&d_out, (size_t)n * 32 * sizeof(double)));
-    HIP_TRY(hipMemset(s->counters, 0, sizeof(Counters)));
+    HIP_TRY(hipMemsetAsync(w.counters, 0, sizeof(Counters), w.stream));
     uint32_t blocks = (n + 255) / 256;
-    if (s->has_csg) hipLaunchKernelGGL((k_probe<true>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->R, d_out, s->counters);
-    else hipLaunchKernelGGL((k_probe<false>), dim3(blocks), dim3(256), 0, 0, s->dev, n, s->R, d_out, s->counters);
+    if (s->has_csg) hipLaunchKernelGGL((k_probe<true>), dim3(blocks), dim3(256), 0, w.stream, s->dev, n, w.R, d_out, w.counters);
+    else hipLaunchKernelGGL((k_probe<false>), dim3(blocks), dim3(256), 0, w.stream, s->dev, n, w.R, d_out, w.counters);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 32 * sizeof(double), hipMemcpyDeviceToHost);
     Counters c{};
-    if (e == hipSuccess) e = hipMemcpy(&c, s->counters, sizeof c, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&c, w.counters, sizeof c, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
     if (c.error & 2u) return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed");

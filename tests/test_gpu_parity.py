@@ -92,6 +92,30 @@ def test_render_is_deterministic_and_depth_zero_has_no_secondary_rays():
     assert compare(c, ref)[0] == 0
 
 
+@pytest.mark.parametrize("scene,depth", [("scenes/chapter11.yaml", 30), ("scenes/area-light.yaml", 5)])
+def test_tuning_options_do_not_change_the_image(scene, depth):
+    """Tiny chunks, a record budget that forces chunks to be split and the budget to grow, one or
+    two streams, a small grid: every setting must give the default's image bit for bit."""
+    g, _ = pair(scene, 0.3)
+    seeds = g.row_seeds()
+    base, st0 = g.render(depth, seeds)
+    for opts in ({ra.OPT_STREAMS: 1}, {ra.OPT_STREAMS: 2, ra.OPT_CHUNK_PIXELS: 8 * g.width},
+                 {ra.OPT_CHUNK_PIXELS: 24 * g.width, ra.OPT_RECS_PER_PIXEL: 1, ra.OPT_GRID_BLOCKS: 7},
+                 {ra.OPT_STREAMS: 1, ra.OPT_CHUNK_PIXELS: 8 * g.width, ra.OPT_RECS_PER_PIXEL: 1}):
+        h, _ = pair(scene, 0.3)
+        for k, v in opts.items():
+            h.set_option(k, v)
+        c, st = h.render(depth, seeds)
+        assert np.array_equal(c.pixels.view(np.uint64), base.pixels.view(np.uint64)), opts
+        assert np.array_equal(c.rgb8, base.rgb8)
+        assert (st["secondary_rays"], st["shadow_rays"], st["shade_hits"]) == (
+            st0["secondary_rays"], st0["shadow_rays"], st0["shade_hits"]), opts
+        if ra.OPT_CHUNK_PIXELS in opts:
+            assert st["chunks"] > 1
+    with pytest.raises(ra.RtError):
+        g.set_option(ra.OPT_STREAMS, 3)
+
+
 def test_full_size_headline_frame_properties():
     """chapter11 at 10000x5000, depth 30: far too large for the oracle as a whole, so check
     (a) 24 evenly spaced rows against the oracle, 8-bit exact and within the colour tolerance,
