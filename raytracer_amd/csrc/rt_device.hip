@@ -1130,8 +1130,9 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
     const uint32_t idx = first + threadIdx.x;
     bool on = idx < total;
     const uint32_t rec_idx = on ? idx : 0;
-    on = on && A.R.hit_pos[rec_idx] != NONE;
-    const V3 over = on ? mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]) : mk(0.0, 0.0, 0.0);
+    const uint32_t hp = A.R.hit_pos[rec_idx];
+    const V3 over = mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]);  // fetched beside hit_pos, not after it
+    on = on && hp != NONE;
     Rng rng;
     rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
@@ -1194,6 +1195,10 @@ DEV uint8_t to_u8(double c) {
     return (uint8_t)round(cl * 255.0);
 }
 
+// pow() is by far the largest register user of k_shade; out of line it only costs its registers
+// while it runs (155 instead of 168+ VGPRs for the kernel, no spills).
+__device__ __noinline__ double shade_pow(double x, double y) { return pow(x, y); }
+
 // colour_at of every ray of one level, deepest level first: the surface colour, Σ over lights of
 // Material::lighting (world.rs:58-70, material.rs:47-87) with pattern_at(object, over_point)
 // (pattern/mod.rs:83-87), plus the colours of the spawned rays (world.rs:72-86,144,176).  No tree
@@ -1208,13 +1213,16 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
     const uint32_t idx = first + threadIdx.x;
     const bool on = idx < lv.n;
     const uint32_t rec = lv.base + (on ? idx : 0);
+    // every column of the record is fetched before the hit test so that the loads overlap
+    // (a miss wastes them, but misses are rare and the kernel is bound by load latency)
     const uint32_t hit_pos = on ? A.R.hit_pos[rec] : NONE;
+    const V3 over = mk(A.R.px[rec], A.R.py[rec], A.R.pz[rec]), normal = mk(A.R.nx[rec], A.R.ny[rec], A.R.nz[rec]);
+    const V3 eye = -mk(A.R.dx[rec], A.R.dy[rec], A.R.dz[rec]);
+    const uint32_t cr_raw = A.R.child_refl[rec], ct_raw = A.R.child_refr[rec];
     uint32_t flops = 0;
     V3 colour = mk(0.0, 0.0, 0.0);
     if (hit_pos != NONE) {
-        const V3 over = mk(A.R.px[rec], A.R.py[rec], A.R.pz[rec]), normal = mk(A.R.nx[rec], A.R.ny[rec], A.R.nz[rec]);
-        const V3 eye = -mk(A.R.dx[rec], A.R.dy[rec], A.R.dz[rec]);
-        const uint32_t cr = A.R.child_refl[rec], ct = A.R.child_refr[rec];
+        const uint32_t cr = cr_raw, ct = ct_raw;
         const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
         const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
         const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
@@ -1256,7 +1264,7 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
                     V3 rv = -reflect(lv, normal);
                     double rde = dot(rv, eye);
                     if (rde > 0.0) {
-                        double factor = pow(rde, m_shininess);
+                        double factor = shade_pow(rde, m_shininess);
                         specular = specular + (lint * m_specular) * factor;
                     }
                 }
