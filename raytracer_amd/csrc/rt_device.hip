@@ -44,6 +44,9 @@ namespace {
 
 // ---------------------------------------------------------------- basics
 constexpr double EPS = 2.220446049250313e-16;  // f64::EPSILON
+// Safety margins of the device-only culling tests: far above the rounding error of an intersection
+// distance (~1e-15 relative), far below anything visible.
+constexpr double CULL_REL = 1e-9, CULL_ABS = 1e-9;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int CSG_CAP = 32;        // intersections buffered inside one outermost csg
 constexpr int CSG_DEPTH = 6;       // nested csg levels
@@ -128,6 +131,7 @@ struct DevScene {
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
     const double* tri_normals;  // n_tris*9
+    const double* cull;         // n_leaves*6: bounding sphere centre, radius, radius^2 (world space), unused
     const uint32_t* csg_op;
     const uint64_t* csg_bits;
     const double* mat;          // n_materials*8: 7 scalars, pattern root (as integer value)
@@ -387,8 +391,10 @@ struct NoRecord {  // shadow rays only need the closest hit
 
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
-// object/csg/mod.rs:57-106).  `record` is wave-uniform.
-template <bool HAS_CSG, class Buf>
+// object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
+// change the closest hit or what sorts before it (w.arrival then no longer counts every
+// intersection of the reference's list; rt_probe, which reports that count, walks without it).
+template <bool HAS_CSG, bool CULL, class Buf>
 DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
                   bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
@@ -480,6 +486,9 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                                      cld(streamd, i * 8 + 5), cld(streamd, i * 8 + 6), cld(streamd, i * 8 + 7), t0, t1);
             if (act && count) flops += F_BOX;
             uint32_t end = clu(S.stream, i * 16 + 1);
+            // Beyond the reference's test: a box entered after the closest hit so far cannot hold a
+            // closer one (nor anything that sorts before it), so its subtree is skipped as well.
+            if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             if (act && !hit) skip_until = end;
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && act && hit) {
@@ -498,6 +507,28 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             continue;
         }
         // a leaf
+        if (CULL && (w0 & (1u << 10))) {
+            // Device-only culling with the leaf's bounding sphere (centre c, radius r, world space):
+            // no lane's ray can reach it, or reach it before its closest hit so far, or (for shapes
+            // that are always entered and left) it lies wholly behind the origin.  Such intersections
+            // can neither become the hit nor sort before it, so the test is skipped for the wave.
+            const uint32_t cb0 = clu(S.stream, i * 16 + 2) * 6;
+            const V3 oc = mk(cld(S.cull, cb0 + 0), cld(S.cull, cb0 + 1), cld(S.cull, cb0 + 2)) - ray.o;
+            const double r = cld(S.cull, cb0 + 3), r2 = cld(S.cull, cb0 + 4);
+            const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
+            const bool outside = cc > r2;
+            const bool miss = outside && b * b < dd * (cc - r2);
+            const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
+            // entry parameter >= b/dd - r/|d|, and |d| <= |dx| + |dy| + |dz|
+            const bool beyond = w.pos != NONE && b - r * (fabs(ray.d.x) + fabs(ray.d.y) + fabs(ray.d.z)) > (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+            if (__ballot(act && !(miss || behind || beyond)) == 0ull) {
+                // the reference would have run the test: it still counts as algorithmic work
+                if (act && count)
+                    flops += F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE);
+                i += 2;
+                continue;
+            }
+        }
         LeafHits h;
         h.n = 0;
         uint32_t f = F_XFORM;
@@ -809,18 +840,30 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
                              uint32_t hit_pos, uint32_t hit_cls) {
     constexpr int N = REC_CAP;
     const int S = cb.stride;
+    // the longest list of the wave bounds every loop below (wave-uniform, so the unrolled
+    // iterations past it are skipped by a scalar branch)
+    int nmax = 0;
+#pragma unroll
+    for (int k = N; k >= 1; k--)
+        if (nmax == 0 && __ballot(need && n >= k) != 0ull) nmax = k;
     double t[N];
     uint32_t p[N], c[N];
     bool v[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        t[k] = cb.t[k * S]; p[k] = cb.pos[k * S]; c[k] = cb.cls[k * S];
-        v[k] = need && k < n && t[k] < hit_t;
+        t[k] = 0.0; p[k] = NONE; c[k] = NONE; v[k] = false;
+        if (k < nmax) {
+            t[k] = cb.t[k * S]; p[k] = cb.pos[k * S]; c[k] = cb.cls[k * S];
+            v[k] = need && k < n && t[k] < hit_t;
+        }
     }
     // early end of the walk (rare): the first entry in sorted order that equals the hit
     bool m[N], any_m = false;
 #pragma unroll
-    for (int k = 0; k < N; k++) { m[k] = v[k] && c[k] == hit_cls && approx_eq(t[k], hit_t); any_m = any_m || m[k]; }
+    for (int k = 0; k < N; k++) {
+        m[k] = false;
+        if (k < nmax) { m[k] = v[k] && c[k] == hit_cls && approx_eq(t[k], hit_t); any_m = any_m || m[k]; }
+    }
     if (__ballot(any_m) != 0ull) {
         bool have = false;
         double st = 0.0;
@@ -841,27 +884,34 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
     bool cand[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        bool odd = false, last = true;
+        cand[i] = false;
+        if (i < nmax) {
+            bool odd = false, last = true;
 #pragma unroll
-        for (int j = 0; j < N; j++) {
-            bool same = v[j] && c[j] == c[i];
-            odd = odd != same;
-            if (j != i) {
-                bool later = j > i ? t[j] >= t[i] : t[j] > t[i];
-                if (same && later) last = false;
+            for (int j = 0; j < N; j++) {
+                if (j < nmax) {
+                    bool same = v[j] && c[j] == c[i];
+                    odd = odd != same;
+                    if (j != i) {
+                        bool later = j > i ? t[j] >= t[i] : t[j] > t[i];
+                        if (same && later) last = false;
+                    }
+                }
             }
+            cand[i] = v[i] && odd && last;
         }
-        cand[i] = v[i] && odd && last;
     }
     bool have1 = false, have2 = false, hit_present = false;
     double t1 = 0.0, t2 = 0.0;
     uint32_t n1_pos = NONE, n2_pos = NONE;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        bool is_hit_cls = c[i] == hit_cls;
-        if (cand[i] && (!have1 || t[i] >= t1)) { t1 = t[i]; n1_pos = p[i]; have1 = true; }
-        if (cand[i] && is_hit_cls) hit_present = true;
-        if (cand[i] && !is_hit_cls && (!have2 || t[i] >= t2)) { t2 = t[i]; n2_pos = p[i]; have2 = true; }
+        if (i < nmax) {
+            bool is_hit_cls = c[i] == hit_cls;
+            if (cand[i] && (!have1 || t[i] >= t1)) { t1 = t[i]; n1_pos = p[i]; have1 = true; }
+            if (cand[i] && is_hit_cls) hit_present = true;
+            if (cand[i] && !is_hit_cls && (!have2 || t[i] >= t2)) { t2 = t[i]; n2_pos = p[i]; have2 = true; }
+        }
     }
     if (!hit_present) n2_pos = hit_pos;  // the hit object was pushed last
     N1N2 r;
@@ -987,7 +1037,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    traverse<HAS_CSG>(S, ray, on, record, w, buf, flops, true, err);
+    traverse<HAS_CSG, true>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -1159,7 +1209,7 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
                 sr.o = over;
                 sr.d = normalise(vec);
                 Walk w = walk_init();
-                traverse<HAS_CSG>(S, sr, on, false, w, NoRecord{}, flops, true, err);
+                traverse<HAS_CSG, true>(S, sr, on, false, w, NoRecord{}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
                 bool shadowed = false;
                 if (on && w.pos != NONE) {
@@ -1440,9 +1490,9 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
             jr.d = normalise(vec);
             jon = hit;
             w = walk_init();
-            traverse<HAS_CSG>(S, jr, jon, false, w, NoRecord{}, flops, false, err);
+            traverse<HAS_CSG, true>(S, jr, jon, false, w, NoRecord{}, flops, false, err);
         } else {
-            traverse<HAS_CSG>(S, jr, jon, true, w, buf, flops, false, err);
+            traverse<HAS_CSG, false>(S, jr, jon, true, w, buf, flops, false, err);
         }
         if (job == 0) {
             if (w.nan_seen && w.arrival >= 2) err |= 4u;
@@ -1509,6 +1559,76 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
         if (e_ != hipSuccess)                                                                 \
             return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
+
+// World-space bounding sphere {centre, radius, radius^2} of a bounded leaf, from rows 0-2 of its
+// inverse transformation; false for unbounded shapes (plane, untruncated cylinder / cone) and
+// degenerate matrices.  The radius is padded: culling only has to be conservative.
+bool bounding_sphere(uint32_t shape, const double* inv, double mn, double mx, double* out) {
+    if (shape == RT_PLANE || shape == RT_TRIANGLE) return false;
+    double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
+    if (shape == RT_CYLINDER || shape == RT_CONE) {
+        if (!std::isfinite(mn) || !std::isfinite(mx)) return false;
+        double rad = shape == RT_CYLINDER ? 1.0 : std::max(std::fabs(mn), std::fabs(mx));
+        lo[0] = lo[2] = -rad; hi[0] = hi[2] = rad;
+        lo[1] = std::min(mn, mx); hi[1] = std::max(mn, mx);
+    }
+    // forward matrix A (3x3) and translation c: world = A * object + c
+    const double a = inv[0], b = inv[1], c = inv[2], e = inv[4], f = inv[5], g = inv[6], k = inv[8], l = inv[9], m = inv[10];
+    const double det = a * (f * m - g * l) - b * (e * m - g * k) + c * (e * l - f * k);
+    if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return false;
+    const double A[3][3] = {{(f * m - g * l) / det, (c * l - b * m) / det, (b * g - c * f) / det},
+                            {(g * k - e * m) / det, (a * m - c * k) / det, (c * e - a * g) / det},
+                            {(e * l - f * k) / det, (b * k - a * l) / det, (a * f - b * e) / det}};
+    const double t[3] = {inv[3], inv[7], inv[11]};
+    double centre_obj[3] = {(lo[0] + hi[0]) / 2, (lo[1] + hi[1]) / 2, (lo[2] + hi[2]) / 2};
+    double centre[3];
+    for (int r = 0; r < 3; r++) {
+        centre[r] = 0.0;
+        for (int q = 0; q < 3; q++) centre[r] += A[r][q] * (centre_obj[q] - t[q]);  // A * (p - t') with t' = inv translation
+    }
+    // world = A * (object - inv_translation_in_object_terms): inv is X_obj = I3 * X_world + t, so X_world = A * (X_obj - t)
+    double radius = 0.0;
+    if (shape == RT_SPHERE) {
+        // largest singular value of A by power iteration on A^T A, from three starting vectors
+        double sigma2 = 0.0;
+        const double starts[3][3] = {{1.0, 0.3, 0.1}, {0.1, 1.0, 0.3}, {0.3, 0.1, 1.0}};
+        for (const auto& s0 : starts) {
+            double v[3] = {s0[0], s0[1], s0[2]};
+            for (int it = 0; it < 64; it++) {
+                double n0 = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                if (!(n0 > 0.0)) break;
+                for (int r = 0; r < 3; r++) v[r] /= n0;
+                double w[3] = {0, 0, 0}, u[3] = {0, 0, 0};
+                for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) w[r] += A[r][q] * v[q];
+                for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) u[r] += A[q][r] * w[q];
+                double n = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+                sigma2 = std::max(sigma2, n);
+                for (int r = 0; r < 3; r++) v[r] = u[r];
+            }
+        }
+        // the iteration converges from below; Frobenius bounds it from above
+        double fro = 0.0;
+        for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++) fro += A[r][q] * A[r][q];
+        radius = std::min(std::sqrt(sigma2) * 1.01, std::sqrt(fro));
+        if (!(radius > 0.0)) radius = std::sqrt(fro);
+    } else {
+        for (int corner = 0; corner < 8; corner++) {
+            double p[3] = {(corner & 1 ? hi[0] : lo[0]) - centre_obj[0], (corner & 2 ? hi[1] : lo[1]) - centre_obj[1],
+                           (corner & 4 ? hi[2] : lo[2]) - centre_obj[2]};
+            double q2 = 0.0;
+            for (int r = 0; r < 3; r++) {
+                double x = A[r][0] * p[0] + A[r][1] * p[1] + A[r][2] * p[2];
+                q2 += x * x;
+            }
+            radius = std::max(radius, std::sqrt(q2));
+        }
+    }
+    radius = radius * (1.0 + 1e-6) + 1e-9;
+    if (!std::isfinite(radius) || !std::isfinite(centre[0]) || !std::isfinite(centre[1]) || !std::isfinite(centre[2])) return false;
+    out[0] = centre[0]; out[1] = centre[1]; out[2] = centre[2];
+    out[3] = radius; out[4] = radius * radius; out[5] = 0.0;
+    return true;
+}
 
 template <class T>
 int upload(const std::vector<T>& host, T** dev) {
@@ -1887,7 +2007,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     }
     unit_of[d->n_nodes] = units;
     std::vector<uint32_t> stream((size_t)(units + 4) * 16, 0);  // padded: the walk may read one record ahead
-    std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0);
+    std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0), cull((size_t)d->n_leaves * 6, 0.0);
+    auto inside_csg = [&](uint32_t node) {
+        for (uint32_t j = 0; j < node; j++)
+            if (d->node_kind[j] == RT_NODE_CSG && d->node_skip[j] > node) return true;
+        return false;
+    };
     std::map<std::vector<uint64_t>, uint32_t> xform_ids;
     bool has_csg = false;
     for (uint32_t i = 0; i < d->n_nodes; i++) {
@@ -1921,6 +2046,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 for (int k = 0; k < 12; k++) recd[2 + k] = inv[k];
                 recd[14] = d->leaf_param[(size_t)leaf * 3 + 0];
                 recd[15] = d->leaf_param[(size_t)leaf * 3 + 1];
+                if (bounding_sphere(shape, inv, recd[14], recd[15], &cull[(size_t)leaf * 6])) {
+                    rec[0] |= 1u << 10;
+                    // a sphere or cube outside any csg is always entered and left: wholly behind the
+                    // origin it toggles the container list twice, i.e. not at all
+                    if ((shape == RT_SPHERE || shape == RT_CUBE) && !inside_csg(i)) rec[0] |= 1u << 11;
+                }
             }
         } else {
             bool csg = d->node_kind[i] == RT_NODE_CSG;
@@ -1978,7 +2109,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->dev.flags = 0;
     for (uint32_t i = 0; i < d->n_materials; i++)
         if (d->material[(size_t)i * 7 + 5] != 0.0) s->dev.flags |= 1u;
-    UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
+    UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(cull, cull); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
     UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);
     UP(light_meta, light_meta);
 #undef UP
