@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1 or 2)")
     ap.add_argument("--grid-blocks", type=int, default=None)
+    ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane")
     ap.add_argument("--chunk-pixels", type=int, default=None)
     args = ap.parse_args()
 
@@ -90,6 +91,8 @@ def main():
     scene.set_option(ra.OPT_STREAMS, args.streams)
     if args.grid_blocks:
         scene.set_option(ra.OPT_GRID_BLOCKS, args.grid_blocks)
+    if args.traversal is not None:
+        scene.set_option(ra.OPT_TRAVERSAL, args.traversal)
     if args.chunk_pixels:
         scene.set_option(ra.OPT_CHUNK_PIXELS, args.chunk_pixels)
     W, H = scene.width, scene.height

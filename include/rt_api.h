@@ -208,9 +208,13 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *                          a multiple of 8 of them
  *   RT_OPT_RECS_PER_PIXEL  ray records reserved per pixel of a chunk (default
  *                          24); a chunk that needs more is split and retried
- *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 2048)
+ *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 4096)
+ *   RT_OPT_TRAVERSAL       0: chosen by tree size (default); 1: the 64 lanes of a
+ *                          wave walk the tree together; 2: every lane walks on
+ *                          its own (large trees, meshes)
  */
-enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4 };
+enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4,
+       RT_OPT_TRAVERSAL = 5 };
 int rt_set_option(rt_scene *scene, int option, uint64_t value);
 
 /* Limits of this build (per-ray list bounds). */

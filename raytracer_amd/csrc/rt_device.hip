@@ -389,6 +389,50 @@ struct NoRecord {  // shadow rays only need the closest hit
     DEV void put(int, double, uint32_t, uint32_t) const {}
 };
 
+// Close every csg of this lane whose subtree ends at or before unit position i: stable sort of
+// what its children delivered, Csg::filter_intersections, then hand the survivors to the enclosing
+// csg's list or (outermost) to `emit`.
+template <class Emit>
+DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uint32_t* cs_end, uint32_t* cs_csg,
+                    int* cs_start, int& clen, int& cs_top, uint32_t& err, Emit& emit, bool want_class) {
+    while (cs_top > 0 && cs_end[cs_top - 1] <= i) {
+        cs_top--;
+        int start = cs_start[cs_top];
+        uint32_t csg = cs_csg[cs_top];
+        // stable insertion sort by t (List::sort, intersection/list.rs:39-50)
+        for (int a = start + 1; a < clen; a++) {
+            double ta = ct[a];
+            uint32_t la = cl[a];
+            if (ta != ta) err |= 4u;
+            int b = a - 1;
+            while (b >= start && ct[b] > ta) { ct[b + 1] = ct[b]; cl[b + 1] = cl[b]; b--; }
+            ct[b + 1] = ta; cl[b + 1] = la;
+        }
+        if (clen - start >= 2 && ct[start] != ct[start]) err |= 4u;
+        // Csg::filter_intersections (object/csg/mod.rs:57-85)
+        uint32_t op = S.csg_op[csg];
+        const uint64_t* bits = S.csg_bits + (size_t)csg * S.class_words;
+        bool in_left = false, in_right = false;
+        int wr = start;
+        for (int a = start; a < clen; a++) {
+            uint32_t cls = S.stream[(size_t)cl[a] * 16 + 3];
+            bool left_hit = (bits[cls >> 6] >> (cls & 63)) & 1ull;
+            bool allowed;
+            if (op == RT_CSG_DIFFERENCE) allowed = (left_hit && !in_right) || (!left_hit && in_left);
+            else if (op == RT_CSG_INTERSECTION) allowed = (left_hit && in_right) || (!left_hit && in_left);
+            else allowed = (left_hit && !in_right) || (!left_hit && !in_left);
+            if (allowed) { ct[wr] = ct[a]; cl[wr] = cl[a]; wr++; }
+            if (left_hit) in_left = !in_left; else in_right = !in_right;
+        }
+        if (cs_top == 0) {
+            for (int a = start; a < wr; a++) emit(true, ct[a], cl[a], want_class ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
+            clen = start;
+        } else {
+            clen = wr;
+        }
+    }
+}
+
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
 // object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
@@ -429,46 +473,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
 
     uint32_t i = 0;
     for (;;) {
-        if constexpr (HAS_CSG) {
-            // Close every csg whose subtree ends at or before position i.
-            while (cs_top > 0 && cs_end[cs_top - 1] <= i) {
-                cs_top--;
-                int start = cs_start[cs_top];
-                uint32_t csg = cs_csg[cs_top];
-                // stable insertion sort by t (List::sort, intersection/list.rs:39-50)
-                for (int a = start + 1; a < clen; a++) {
-                    double ta = ct[a];
-                    uint32_t la = cl[a];
-                    if (ta != ta) err |= 4u;
-                    int b = a - 1;
-                    while (b >= start && ct[b] > ta) { ct[b + 1] = ct[b]; cl[b + 1] = cl[b]; b--; }
-                    ct[b + 1] = ta; cl[b + 1] = la;
-                }
-                if (clen - start >= 2 && ct[start] != ct[start]) err |= 4u;
-                // Csg::filter_intersections (object/csg/mod.rs:57-85)
-                uint32_t op = S.csg_op[csg];
-                const uint64_t* bits = S.csg_bits + (size_t)csg * S.class_words;
-                bool in_left = false, in_right = false;
-                int wr = start;
-                for (int a = start; a < clen; a++) {
-                    uint32_t cls = S.stream[(size_t)cl[a] * 16 + 3];
-                    bool left_hit = (bits[cls >> 6] >> (cls & 63)) & 1ull;
-                    bool allowed;
-                    if (op == RT_CSG_DIFFERENCE) allowed = (left_hit && !in_right) || (!left_hit && in_left);
-                    else if (op == RT_CSG_INTERSECTION) allowed = (left_hit && in_right) || (!left_hit && in_left);
-                    else allowed = (left_hit && !in_right) || (!left_hit && !in_left);
-                    if (allowed) { ct[wr] = ct[a]; cl[wr] = cl[a]; wr++; }
-                    if (left_hit) in_left = !in_left; else in_right = !in_right;
-                }
-                if (cs_top == 0) {
-                    for (int a = start; a < wr; a++)
-                        emit(true, ct[a], cl[a], (Buf::enabled && record) ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
-                    clen = start;
-                } else {
-                    clen = wr;
-                }
-            }
-        }
+        if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
         if (i >= n) break;
         bool act = skip_until <= i;
         if (__ballot(act) == 0ull) {
@@ -571,6 +576,130 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
         }
         i += 2;
     }
+}
+
+// The same walk with one position per lane, for trees too large for the wave to walk together
+// (meshes): each lane follows its own path through the skip links, loading nodes with vector
+// loads, so a lane only pays for the boxes and leaves its own ray reaches.  Lanes at different
+// kinds of node take turns within an iteration.
+template <bool HAS_CSG, bool CULL, class Buf>
+DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+                       bool count, uint32_t& err) {
+    const uint32_t n = S.n_units;
+    double ct[HAS_CSG ? CSG_CAP : 1];
+    uint32_t cl[HAS_CSG ? CSG_CAP : 1];
+    uint32_t cs_end[HAS_CSG ? CSG_DEPTH : 1], cs_csg[HAS_CSG ? CSG_DEPTH : 1];
+    int cs_start[HAS_CSG ? CSG_DEPTH : 1];
+    int clen = 0, cs_top = 0;
+    (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
+        if (on) {
+            if (tt != tt) w.nan_seen = true;
+            const bool below = w.pos == NONE || tt < w.t;
+            if constexpr (Buf::enabled) {
+                if (record && below) {
+                    if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
+                }
+            }
+            if (tt > 0.0 && below) { w.t = tt; w.pos = p; }
+            w.arrival++;
+        }
+    };
+    uint32_t cur_xform = NONE;  // per lane: the mesh matrix tri_ray was made with
+    Ray tri_ray = ray;
+    uint32_t i = lane_on ? 0u : n;
+    for (;;) {
+        if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
+        const bool act = i < n;
+        if (__ballot(act) == 0ull) break;
+        const uint32_t* rec = S.stream + (size_t)(act ? i : 0u) * 16;
+        const double* recd = (const double*)rec;
+        const uint32_t w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+        const uint32_t kind = w0 & 0xFFu;
+        if (act && kind >= K_GROUP) {
+            double t0, t1;
+            bool hit = box_intersect(ray, recd[2], recd[3], recd[4], recd[5], recd[6], recd[7], t0, t1);
+            if (count) flops += F_BOX;
+            if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
+            uint32_t next = hit ? i + 1 : w1;
+            if constexpr (HAS_CSG) {
+                if (kind == K_CSG && hit) {
+                    if (cs_top < CSG_DEPTH) {
+                        cs_end[cs_top] = w1; cs_csg[cs_top] = w2; cs_start[cs_top] = clen;
+                        cs_top++;
+                    } else {
+                        err |= 2u;
+                        next = w1;
+                    }
+                }
+            }
+            i = next;
+        } else if (act) {
+            bool culled = false;
+            if (CULL && (w0 & (1u << 10))) {  // see the wave-uniform walk
+                const double* cs = S.cull + (size_t)w2 * 6;
+                const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
+                const double r = cs[3], r2 = cs[4];
+                const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
+                const bool outside = cc > r2;
+                const bool miss = outside && b * b < dd * (cc - r2);
+                const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
+                const bool beyond = w.pos != NONE && b - r * (fabs(ray.d.x) + fabs(ray.d.y) + fabs(ray.d.z)) > (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+                culled = miss || behind || beyond;
+                if (culled && count)
+                    flops += F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE);
+            }
+            if (!culled) {
+                LeafHits h;
+                h.n = 0;
+                uint32_t f = F_XFORM;
+                if (kind == RT_TRIANGLE) {
+                    const uint32_t xf = rec[4];
+                    if (xf != cur_xform) {
+                        cur_xform = xf;
+                        const double* m = S.xform + (size_t)xf * 12;
+                        tri_ray.o = mul_point_v(m, ray.o);
+                        tri_ray.d = mul_vector_v(m, ray.d);
+                    }
+                    V3 p1 = mk(recd[4], recd[5], recd[6]), e1 = mk(recd[7], recd[8], recd[9]), e2 = mk(recd[10], recd[11], recd[12]);
+                    double t, u, v;
+                    if (triangle_hit(tri_ray, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
+                    f += F_TRI;
+                } else {
+                    Ray r;
+                    r.o = mul_point_v(recd + 2, ray.o);
+                    r.d = mul_vector_v(recd + 2, ray.d);
+                    if (kind == RT_SPHERE) { sphere_hits(r, h); f += F_SPHERE; }
+                    else if (kind == RT_PLANE) { plane_hits(r, h); f += F_PLANE; }
+                    else if (kind == RT_CUBE) { cube_hits(r, h); f += F_BOX; }
+                    else if (kind == RT_CYLINDER) { cylinder_hits(r, recd[14], recd[15], (w0 >> 9) & 1u, h); f += F_CYL; }
+                    else { cone_hits(r, recd[14], recd[15], (w0 >> 9) & 1u, h); f += F_CONE; }
+                }
+                if (count) flops += f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    bool on = k < h.n;
+                    if constexpr (HAS_CSG) {
+                        if (on && cs_top > 0) {
+                            if (clen < CSG_CAP) { ct[clen] = h.t[k]; cl[clen] = i; clen++; } else err |= 2u;
+                            on = false;
+                        }
+                    }
+                    emit(on, h.t[k], i, w3);
+                }
+            }
+            i += 2;
+        }
+    }
+}
+
+// Chooses the walk: small trees are walked by the wave together (scalar loads, no divergence),
+// large ones lane by lane.
+template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf>
+DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+                   bool count, uint32_t& err) {
+    if constexpr (PER_LANE) traverse_lane<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
+    else traverse<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
 }
 
 // ---------------------------------------------------------------- patterns
@@ -979,7 +1108,7 @@ DEV uint32_t global_row(const LevelArgs& A, uint32_t local_row) {
 
 // colour_at for every ray of one level, minus the shading and the recursion
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
-template <bool PRIMARY, bool HAS_CSG>
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
 __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -1037,7 +1166,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    traverse<HAS_CSG, true>(S, ray, on, record, w, buf, flops, true, err);
+    walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -1169,7 +1298,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 
 // Lightable::intensity_at for every shade point and light (light/point.rs:27-38, light/area.rs:75-90):
 // one closest-hit shadow ray per light sample (World::is_shadowed, world.rs:109-126).
-template <bool HAS_CSG>
+template <bool HAS_CSG, bool PER_LANE>
 __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
@@ -1209,7 +1338,7 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
                 sr.o = over;
                 sr.d = normalise(vec);
                 Walk w = walk_init();
-                traverse<HAS_CSG, true>(S, sr, on, false, w, NoRecord{}, flops, true, err);
+                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, on, false, w, NoRecord{}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
                 bool shadowed = false;
                 if (on && w.pos != NONE) {
@@ -1676,6 +1805,7 @@ struct Workspace {
     size_t row_cap = 0, row_base_cap = 0;
 };
 constexpr int MAX_STREAMS = 2;
+constexpr uint32_t PER_LANE_MIN_UNITS = 512;  // trees above this many 64-byte units are walked lane by lane
 
 struct rt_scene {
     DevScene dev{};
@@ -1684,7 +1814,8 @@ struct rt_scene {
     int device = 0;
     Workspace ws[MAX_STREAMS];
     int n_streams = 2;
-    uint32_t grid_blocks = 2048;        // blocks of every level kernel (they stride over the rays)
+    int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane
+    uint32_t grid_blocks = 4096;        // blocks of every level kernel (they stride over the rays)
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
@@ -1763,7 +1894,7 @@ struct FirstLevel {   // where the first level's rays come from
 // shadow rays, then the colours from the deepest level up (level 0 writes the outputs).  Nothing
 // here waits for the GPU unless the scene has an area light (its rng order needs the level sizes
 // on the host).  `slot` selects the workspace's ChunkStatus entry and event quadruple.
-template <bool HAS_CSG>
+template <bool HAS_CSG, bool PER_LANE>
 int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
                 uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
     hipStream_t st = w.stream;
@@ -1786,9 +1917,9 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         A.level = level;
         A.depth_remaining = depth - level;
         if (first.primary && level == 0)
-            hipLaunchKernelGGL((k_trace<true, HAS_CSG>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+            hipLaunchKernelGGL((k_trace<true, HAS_CSG, PER_LANE>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
         else
-            hipLaunchKernelGGL((k_trace<false, HAS_CSG>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+            hipLaunchKernelGGL((k_trace<false, HAS_CSG, PER_LANE>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
     }
     tot.trace_launches += n_levels;
     HIP_TRY(hipGetLastError());
@@ -1837,7 +1968,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         }
     }
 
-    hipLaunchKernelGGL((k_shadow<HAS_CSG>), grid, block, 0, st, s->dev, A);
+    hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
@@ -1853,8 +1984,13 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
 
 int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
                          double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
-    if (s->has_csg) return queue_chunk<true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
-    return queue_chunk<false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    const bool per_lane = s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS);
+    if (s->has_csg) {
+        if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+        return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    }
+    if (per_lane) return queue_chunk<false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    return queue_chunk<false, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
 }
 
 // Wait for a workspace's stream and fetch the status of its first `n_slots` chunks.
@@ -2148,6 +2284,10 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
                 if (w.intensity) (void)hipFree(w.intensity);
                 w.intensity = nullptr; w.intensity_cap = 0;
             }
+            return RT_OK;
+        case RT_OPT_TRAVERSAL:
+            if (value > 2) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave) or 2 (lane)");
+            s->traversal = (int)value;
             return RT_OK;
         case RT_OPT_GRID_BLOCKS:
             if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 1..65536");

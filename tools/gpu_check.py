@@ -14,6 +14,10 @@ def check(name, scale, depth, spheres=False, seed=0, threads=16):
         g = ra.Scene.from_file(f"{ROOT}/scenes/{name}.yaml", scale, seed); o = ol.OracleScene.from_file(f"{ROOT}/scenes/{name}.yaml", scale, seed)
     seeds = g.row_seeds(); oseeds = o.row_seeds()
     assert (seeds == oseeds).all()
+    trav = int(os.environ.get("RT_TRAVERSAL", "0"))
+    if trav:
+        g.set_option(ra.OPT_TRAVERSAL, trav)
+        name = f"{name}[traversal {trav}]"
     t1 = time.time()
     canvas, st = g.render(depth, seeds)
     t2 = time.time()
