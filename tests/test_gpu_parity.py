@@ -92,6 +92,26 @@ def test_render_is_deterministic_and_depth_zero_has_no_secondary_rays():
     assert compare(c, ref)[0] == 0
 
 
+@pytest.mark.parametrize("scene,scale,depth", [
+    ("scenes/chapter11.yaml", 0.3, 30), ("scenes/chapter16.yaml", 0.3, 5), ("scenes/chapter13.yaml", 0.3, 5),
+    ("scenes/chapter15.yaml", 0.2, 5), ("scenes/bounding-box.yaml", 0.15, 5), ("scenes/area-light.yaml", 0.25, 5)])
+def test_both_tree_walks_give_the_same_image(scene, scale, depth):
+    """The wave-uniform walk and the lane-by-lane walk (meshes) are two schedules of the same
+    arithmetic: bit-identical f64 frames and ray counts, whichever the tree size would select."""
+    frames = []
+    for mode in (1, 2):
+        g, _ = pair(scene, scale)
+        g.set_option(ra.OPT_TRAVERSAL, mode)
+        seeds = g.row_seeds()
+        c, st = g.render(depth, seeds)
+        frames.append((c, st))
+    (a, sa), (b, sb) = frames
+    assert np.array_equal(a.pixels.view(np.uint64), b.pixels.view(np.uint64))
+    assert np.array_equal(a.rgb8, b.rgb8)
+    for key in ("secondary_rays", "shadow_rays", "shade_hits", "flop_trace", "flop_shadow"):
+        assert sa[key] == sb[key], key
+
+
 @pytest.mark.parametrize("scene,depth", [("scenes/chapter11.yaml", 30), ("scenes/area-light.yaml", 5)])
 def test_tuning_options_do_not_change_the_image(scene, depth):
     """Tiny chunks, a record budget that forces chunks to be split and the budget to grow, one or
