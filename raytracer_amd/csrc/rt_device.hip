@@ -708,6 +708,14 @@ DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record,
 // evaluated with an explicit stack instead of recursion.  A frame is a two-child node
 // (gradient, radial gradient, blend) waiting for its children; choosing kinds (stripe, ring,
 // checker) just descend.  Trees deeper than PAT_DEPTH are rejected by rt_scene_create.
+// `v % 2.0 == 0.0` of the reference (Rust's `%` is fmod) for an integer-valued v: fmod is exact,
+// so it is zero exactly when v is an even integer.  Every double of magnitude >= 2^53 is an even
+// integer; NaN and the infinities give NaN % 2.0, which is not zero.
+DEV bool is_even(double v) {
+    const double a = fabs(v);
+    if (!(a < 9007199254740992.0)) return a == a && a < __builtin_huge_val();
+    return (((long long)a) & 1ll) == 0;
+}
 struct PatTables { const uint32_t* pat_meta; const double* pat_inv; const double* pat_col; };
 DEV V3 pattern_eval(PatTables S, uint32_t root, V3 object_point) {
     uint32_t f_node[PAT_DEPTH + 1];
@@ -727,9 +735,9 @@ DEV V3 pattern_eval(PatTables S, uint32_t root, V3 object_point) {
                 value = mk(S.pat_col[node * 4 + 0], S.pat_col[node * 4 + 1], S.pat_col[node * 4 + 2]);
                 break;
             }
-            if (kind == RT_PAT_STRIPE) node = fmod(floor(pp.x), 2.0) == 0.0 ? a : b;
-            else if (kind == RT_PAT_RING) node = fmod(floor(hypot(pp.x, pp.z)), 2.0) == 0.0 ? a : b;
-            else if (kind == RT_PAT_CHECKER) node = fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0) == 0.0 ? a : b;
+            if (kind == RT_PAT_STRIPE) node = is_even(floor(pp.x)) ? a : b;
+            else if (kind == RT_PAT_RING) node = is_even(floor(hypot(pp.x, pp.z))) ? a : b;
+            else if (kind == RT_PAT_CHECKER) node = is_even(floor(pp.x) + floor(pp.y) + floor(pp.z)) ? a : b;
             else {
                 if (top > PAT_DEPTH) return mk(0.0, 0.0, 0.0);
                 f_node[top] = node; f_stage[top] = 0; f_pp[top] = pp; top++;
@@ -1428,7 +1436,11 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
             V3 col = cmul(pat, lint);
             V3 ambient = col * m_ambient;
             V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
-            for (uint32_t k = 0; k < samples; k++) {
+            // With intensity 0 the diffuse and specular sums are multiplied by zero (they are finite
+            // for a non-negative shininess): the loop is skipped, only its rng draws are taken.
+            const bool dark = intensity == 0.0 && m_shininess >= 0.0;
+            if (dark && is_area) rng_skip(rng, 2 * samples);
+            for (uint32_t k = 0; k < (dark ? 0u : samples); k++) {
                 V3 lp = l0;
                 if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
                     double r1 = rng_unit(rng);
