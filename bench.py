@@ -174,7 +174,8 @@ def main():
                 stats, _ = step()
                 torch.cuda.synchronize()
                 scene.set_option(ra.OPT_STREAMS, args.streams)
-            flop = stats["flop_trace"]
+            fused = bool(stats["fused_shadows"])  # k_trace also casts the shadow rays (no area light)
+            flop = stats["flop_trace"] + (stats["flop_shadow"] if fused else 0)
             ms_k = stats["ms_trace"]
             launches = stats["trace_launches"]
             achieved = flop / (ms_k * 1e-3) / 1e12 if ms_k > 0 else 0.0
@@ -192,7 +193,8 @@ def main():
             alg_bytes = 12 * (primary + secondary) + 144 * secondary + 75 * primary + (48 + 24 + 72 + 16 + 16 * n_lights) * shade
             out["roofline"] = {
                 "bound": "valu_fp64",
-                "kernel": "k_trace (closest hit + n1/n2 + spawn; one launch per recursion level and chunk)",
+                "kernel": "k_trace (closest hit + n1/n2 + spawn" + (" + shadow rays" if fused else "") +
+                          "; one launch per recursion level and chunk)",
                 "measured": "HIP events on the launch stream around each chunk's k_trace launches, in one extra "
                             "single-stream frame after the timed region" if args.streams != 1 else
                             "HIP events on the launch stream around each chunk's k_trace launches, last timed frame",
@@ -207,8 +209,8 @@ def main():
                 "kernel_ms_per_frame": ms_k,
                 "traffic": None,
                 "other_kernels": {
-                    "k_shadow": {"ms_per_frame": stats["ms_shadow"], "algorithmic_flop_per_frame": stats["flop_shadow"],
-                                 "achieved_TFLOPs": stats["flop_shadow"] / (stats["ms_shadow"] * 1e-3) / 1e12 if stats["ms_shadow"] > 0 else 0.0},
+                    "k_shadow": ({"fused_into": "k_trace", "algorithmic_flop_per_frame": stats["flop_shadow"]} if fused else
+                                 {"ms_per_frame": stats["ms_shadow"], "algorithmic_flop_per_frame": stats["flop_shadow"]}),
                     "k_shade": {"ms_per_frame": stats["ms_shade"], "algorithmic_flop_per_frame": stats["flop_light"]},
                 },
                 "hbm": {"algorithmic_bytes_per_frame": alg_bytes,

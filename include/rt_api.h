@@ -142,15 +142,18 @@ typedef struct rt_stats {
                                 spawn, one launch per level), summed over chunks;
                                 with two streams the chunks overlap, so the three
                                 sums can exceed ms_total                           */
-    double ms_shadow;        /* the same for k_shadow (shadow rays, one per chunk) */
+    double ms_shadow;        /* the same for k_shadow (shadow rays, one per chunk;
+                                only launched for scenes with an area light)       */
     double ms_shade;         /* the same for the k_shade launches (patterns + Phong
                                 + the sum with the spawned rays' colours)          */
     uint64_t trace_launches; /* number of k_trace launches                         */
     uint64_t flop_trace;     /* algorithmic f64 FLOP counted on the device in
                                 k_trace / k_shadow / k_shade: op-class counts x the
                                 per-op constants F_* of csrc/rt_device.hip         */
-    uint64_t flop_shadow;
+    uint64_t flop_shadow;    /* shadow-ray walks (inside k_trace when fused_shadows) */
     uint64_t flop_light;
+    uint64_t fused_shadows;  /* 1: k_trace cast the shadow rays itself and ms_shadow
+                                is 0; 0: k_shadow did (scenes with an area light)  */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

@@ -57,7 +57,7 @@ class Stats(C.Structure):
         ("shade_hits", C.c_uint64), ("levels", C.c_uint32), ("chunks", C.c_uint32),
         ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
         ("trace_launches", C.c_uint64), ("flop_trace", C.c_uint64),
-        ("flop_shadow", C.c_uint64), ("flop_light", C.c_uint64),
+        ("flop_shadow", C.c_uint64), ("flop_light", C.c_uint64), ("fused_shadows", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -131,7 +131,7 @@ struct DevScene {
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
     const double* tri_normals;  // n_tris*9
-    const double* cull;         // n_leaves*6: bounding sphere centre, radius, radius^2 (world space), unused
+    const double* cull;         // n_units*6, at a leaf's first unit: bounding sphere centre, radius, radius^2 (world space)
     const uint32_t* csg_op;
     const uint64_t* csg_bits;
     const double* mat;          // n_materials*8: 7 scalars, pattern root (as integer value)
@@ -481,16 +481,27 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             if (i > n) i = n;
             continue;
         }
-        const uint32_t w0 = clu(S.stream, i * 16 + 0);
-        const uint32_t w3 = clu(S.stream, i * 16 + 3);
+        // The whole node (128 bytes: every kind keeps what the walk needs in its first two units)
+        // and its culling sphere are requested together and waited for once; fetching the header
+        // first and the rest by kind would put four to six dependent scalar-load round trips
+        // into every leaf.
+        double q[16], cs[5];
+#pragma unroll
+        for (int k = 0; k < 16; k++) q[k] = cld(streamd, i * 8 + k);
+#pragma unroll
+        for (int k = 0; k < 5; k++) cs[k] = CULL ? cld(S.cull, i * 6 + k) : 0.0;
+        asm volatile("" ::"s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]), "s"(q[8]),
+                     "s"(q[9]), "s"(q[10]), "s"(q[11]), "s"(q[12]), "s"(q[13]), "s"(q[14]), "s"(q[15]), "s"(cs[0]),
+                     "s"(cs[1]), "s"(cs[2]), "s"(cs[3]), "s"(cs[4]));
+        const uint32_t w0 = (uint32_t)__double2loint(q[0]), w1 = (uint32_t)__double2hiint(q[0]);
+        const uint32_t w2 = (uint32_t)__double2loint(q[1]), w3 = (uint32_t)__double2hiint(q[1]);
         const uint32_t kind = w0 & 0xFFu;
         if (kind >= K_GROUP) {
             // Group or csg: cull by the stored box (group/mod.rs:30-32, csg/mod.rs:89-91)
             double t0, t1;
-            bool hit = box_intersect(ray, cld(streamd, i * 8 + 2), cld(streamd, i * 8 + 3), cld(streamd, i * 8 + 4),
-                                     cld(streamd, i * 8 + 5), cld(streamd, i * 8 + 6), cld(streamd, i * 8 + 7), t0, t1);
+            bool hit = box_intersect(ray, q[2], q[3], q[4], q[5], q[6], q[7], t0, t1);
             if (act && count) flops += F_BOX;
-            uint32_t end = clu(S.stream, i * 16 + 1);
+            uint32_t end = w1;
             // Beyond the reference's test: a box entered after the closest hit so far cannot hold a
             // closer one (nor anything that sorts before it), so its subtree is skipped as well.
             if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
@@ -499,7 +510,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                 if (kind == K_CSG && act && hit) {
                     if (cs_top < CSG_DEPTH) {
                         cs_end[cs_top] = end;
-                        cs_csg[cs_top] = clu(S.stream, i * 16 + 2);
+                        cs_csg[cs_top] = w2;
                         cs_start[cs_top] = clen;
                         cs_top++;
                     } else {
@@ -517,9 +528,8 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             // no lane's ray can reach it, or reach it before its closest hit so far, or (for shapes
             // that are always entered and left) it lies wholly behind the origin.  Such intersections
             // can neither become the hit nor sort before it, so the test is skipped for the wave.
-            const uint32_t cb0 = clu(S.stream, i * 16 + 2) * 6;
-            const V3 oc = mk(cld(S.cull, cb0 + 0), cld(S.cull, cb0 + 1), cld(S.cull, cb0 + 2)) - ray.o;
-            const double r = cld(S.cull, cb0 + 3), r2 = cld(S.cull, cb0 + 4);
+            const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
+            const double r = cs[3], r2 = cs[4];
             const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
             const bool outside = cc > r2;
             const bool miss = outside && b * b < dd * (cc - r2);
@@ -538,29 +548,26 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
         h.n = 0;
         uint32_t f = F_XFORM;
         if (kind == RT_TRIANGLE) {
-            uint32_t xf = clu(S.stream, i * 16 + 4);
+            uint32_t xf = (uint32_t)__double2loint(q[2]);
             if (xf != cur_xform) {  // wave-uniform: one transform per mesh matrix
                 cur_xform = xf;
                 tri_ray = to_object_u(S.xform, xf * 12, ray);
             }
-            V3 p1 = mk(cld(streamd, i * 8 + 4), cld(streamd, i * 8 + 5), cld(streamd, i * 8 + 6));
-            V3 e1 = mk(cld(streamd, i * 8 + 7), cld(streamd, i * 8 + 8), cld(streamd, i * 8 + 9));
-            V3 e2 = mk(cld(streamd, i * 8 + 10), cld(streamd, i * 8 + 11), cld(streamd, i * 8 + 12));
+            V3 p1 = mk(q[4], q[5], q[6]), e1 = mk(q[7], q[8], q[9]), e2 = mk(q[10], q[11], q[12]);
             double t, u, v;
             if (triangle_hit(tri_ray, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
             f += F_TRI;
         } else {
-            Ray r = to_object_u(streamd, i * 8 + 2, ray);
+            Ray r;  // Shape::intersect's ray in object space (shape.rs:49-57), rows 0-2 of the inverse in q[2..13]
+            r.o = mk(q[2] * ray.o.x + q[3] * ray.o.y + q[4] * ray.o.z + q[5], q[6] * ray.o.x + q[7] * ray.o.y + q[8] * ray.o.z + q[9],
+                     q[10] * ray.o.x + q[11] * ray.o.y + q[12] * ray.o.z + q[13]);
+            r.d = mk(q[2] * ray.d.x + q[3] * ray.d.y + q[4] * ray.d.z, q[6] * ray.d.x + q[7] * ray.d.y + q[8] * ray.d.z,
+                     q[10] * ray.d.x + q[11] * ray.d.y + q[12] * ray.d.z);
             if (kind == RT_SPHERE) { sphere_hits(r, h); f += F_SPHERE; }
             else if (kind == RT_PLANE) { plane_hits(r, h); f += F_PLANE; }
             else if (kind == RT_CUBE) { cube_hits(r, h); f += F_BOX; }
-            else if (kind == RT_CYLINDER) {
-                cylinder_hits(r, cld(streamd, i * 8 + 14), cld(streamd, i * 8 + 15), (w0 >> 9) & 1u, h);
-                f += F_CYL;
-            } else {
-                cone_hits(r, cld(streamd, i * 8 + 14), cld(streamd, i * 8 + 15), (w0 >> 9) & 1u, h);
-                f += F_CONE;
-            }
+            else if (kind == RT_CYLINDER) { cylinder_hits(r, q[14], q[15], (w0 >> 9) & 1u, h); f += F_CYL; }
+            else { cone_hits(r, q[14], q[15], (w0 >> 9) & 1u, h); f += F_CONE; }
         }
         if (act && count) flops += f;
 #pragma unroll
@@ -637,7 +644,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
         } else if (act) {
             bool culled = false;
             if (CULL && (w0 & (1u << 10))) {  // see the wave-uniform walk
-                const double* cs = S.cull + (size_t)w2 * 6;
+                const double* cs = S.cull + (size_t)i * 6;
                 const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
                 const double r = cs[3], r2 = cs[4];
                 const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
@@ -852,10 +859,11 @@ DEV const double* leaf_inverse(const uint32_t* stream, const double* xform, uint
 
 struct HitGeom { V3 point, normal; int inside; };
 
+
 // point, normal and inside flag of Intersection::prepare_computations (intersection/mod.rs:45-60) with
 // Shape::normal_at (object/shape.rs:60-70) and the per-shape normals (sphere.rs:38-40, plane.rs:26-32,
 // cube.rs:24-40, cylinder.rs:98-108, cone.rs:103-118, triangle.rs:99-104).  `pos` differs per lane.
-__device__ __noinline__ HitGeom hit_geometry(const uint32_t* stream, const double* xform, const double* tri_normals,
+DEV HitGeom hit_geometry(const uint32_t* stream, const double* xform, const double* tri_normals,
                                              Ray ray, double t, uint32_t pos) {
     HitGeom g;
     g.point = ray.o + ray.d * t;
@@ -1114,9 +1122,60 @@ DEV uint32_t global_row(const LevelArgs& A, uint32_t local_row) {
 // All three run as a fixed-size grid whose blocks stride over the work: how many rays a level
 // holds is only known on the device (LevelState).
 
+// The area-light rng stream of one shade point (world.rs:60-70): per light, 2*samples draws for
+// intensity_at's positions (light/area.rs:83) and then 2*samples for lighting's (material.rs:64).
+DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++) (void)rng_next(r); }
+
+// Lightable::intensity_at of one shade point for every light (light/point.rs:27-38,
+// light/area.rs:75-90): one closest-hit shadow ray per light sample (World::is_shadowed,
+// world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
+template <bool HAS_CSG, bool PER_LANE>
+DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, Rng rng, uint32_t& flops,
+                     uint32_t& err, uint32_t& n_shadow) {
+    if (__ballot(on) == 0ull) return;
+    for (uint32_t l = 0; l < S.n_lights; l++) {
+        const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
+        const uint32_t samples = usteps * vsteps;
+        const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
+        const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+        const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
+        const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
+        double unshadowed = 0.0;
+        for (uint32_t k = 0; k < samples; k++) {
+            V3 lp = l0;
+            if (is_area) {  // light/area.rs:48-67: v outer, u inner, r1 before r2
+                double r1 = rng_unit(rng);
+                V3 p = l0 + uc * ((double)(k % usteps) + r1);
+                double r2 = rng_unit(rng);
+                lp = p + vc * ((double)(k / usteps) + r2);
+            }
+            V3 vec = lp - over;
+            double distance = sqrt(dot(vec, vec));
+            Ray sr;
+            sr.o = over;
+            sr.d = normalise(vec);
+            Walk w = walk_init();
+            walk_tree<HAS_CSG, true, PER_LANE>(S, sr, on, false, w, NoRecord{}, flops, true, err);
+            if (w.nan_seen && w.arrival >= 2) err |= 4u;
+            bool shadowed = false;
+            if (on && w.pos != NONE) {
+                bool casts = (S.stream[(size_t)w.pos * 16] >> 8) & 1u;
+                shadowed = casts && w.t < distance;
+            }
+            if (!shadowed) unshadowed += 1.0;
+            if (on) { flops += F_SHADOW; n_shadow++; }
+        }
+        if (on) {
+            double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
+            A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
+        }
+        if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
+    }
+}
+
 // colour_at for every ray of one level, minus the shading and the recursion
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool SHADOWS>
 __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -1134,7 +1193,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
     buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
-    uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0;
+    uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
     const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
                                      : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
@@ -1285,6 +1344,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
 #endif
     n_spawned += n_refl + n_refr;  // wave-uniform
     if (hit) n_shade++;
+    // the shadow rays of this hit, unless the lights need the chunk's rng order first (k_shadow):
+    // their arithmetic fills the issue slots this kernel leaves idle while it waits for memory
+    if constexpr (SHADOWS) {
+        Rng none;
+        none.s0 = none.s1 = none.s2 = none.s3 = 0;
+        intensities<HAS_CSG, PER_LANE>(S, A, hit, rec_idx, over, none, flops_shadow, err, n_shadow);
+    }
     }  // steps
 
     // statistics: one atomic per wave and counter
@@ -1297,15 +1363,20 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
         if (s_shade) atomicAdd(&st->shade, (unsigned long long)s_shade);
         atomicAdd(&st->flop_trace, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
     }
+    if constexpr (SHADOWS) {
+        uint32_t s_shadow = wave_sum_u32(n_shadow);
+        uint32_t sh_lo = wave_sum_u32(flops_shadow & 0xFFFFu), sh_hi = wave_sum_u32(flops_shadow >> 16);
+        if (lane == 0) {
+            StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
+            if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
+            atomicAdd(&st->flop_shadow, (unsigned long long)sh_lo + ((unsigned long long)sh_hi << 16));
+        }
+    }
     if (any_err && err) atomicOr(&A.counters->error, err);
 }
 
-// The area-light rng stream of one shade point (world.rs:60-70): per light, 2*samples draws for
-// intensity_at's positions (light/area.rs:83) and then 2*samples for lighting's (material.rs:64).
-DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++) (void)rng_next(r); }
-
-// Lightable::intensity_at for every shade point and light (light/point.rs:27-38, light/area.rs:75-90):
-// one closest-hit shadow ray per light sample (World::is_shadowed, world.rs:109-126).
+// The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
+// whole chunk first (area lights); otherwise k_trace casts them itself.
 template <bool HAS_CSG, bool PER_LANE>
 __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
@@ -1313,57 +1384,18 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
     const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
     uint32_t flops = 0, err = 0, n_shadow = 0;
     for (uint32_t first = blockIdx.x * 256; first < total; first += gridDim.x * 256) {
-    LOOP_FENCE();
-    const uint32_t idx = first + threadIdx.x;
-    bool on = idx < total;
-    const uint32_t rec_idx = on ? idx : 0;
-    const uint32_t hp = A.R.hit_pos[rec_idx];
-    const V3 over = mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]);  // fetched beside hit_pos, not after it
-    on = on && hp != NONE;
-    Rng rng;
-    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
-    if (__ballot(on) != 0ull) {
-        for (uint32_t l = 0; l < S.n_lights; l++) {
-            const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
-            const uint32_t samples = usteps * vsteps;
-            const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
-            const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
-            const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
-            const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
-            double unshadowed = 0.0;
-            for (uint32_t k = 0; k < samples; k++) {
-                V3 lp = l0;
-                if (is_area) {  // light/area.rs:48-67: v outer, u inner, r1 before r2
-                    double r1 = rng_unit(rng);
-                    V3 p = l0 + uc * ((double)(k % usteps) + r1);
-                    double r2 = rng_unit(rng);
-                    lp = p + vc * ((double)(k / usteps) + r2);
-                }
-                V3 vec = lp - over;
-                double distance = sqrt(dot(vec, vec));
-                Ray sr;
-                sr.o = over;
-                sr.d = normalise(vec);
-                Walk w = walk_init();
-                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, on, false, w, NoRecord{}, flops, true, err);
-                if (w.nan_seen && w.arrival >= 2) err |= 4u;
-                bool shadowed = false;
-                if (on && w.pos != NONE) {
-                    bool casts = (S.stream[(size_t)w.pos * 16] >> 8) & 1u;
-                    shadowed = casts && w.t < distance;
-                }
-                if (!shadowed) unshadowed += 1.0;
-                if (on) { flops += F_SHADOW; n_shadow++; }
-            }
-            if (on) {
-                double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
-                A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
-            }
-            if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
-        }
+        LOOP_FENCE();
+        const uint32_t idx = first + threadIdx.x;
+        bool on = idx < total;
+        const uint32_t rec_idx = on ? idx : 0;
+        const uint32_t hp = A.R.hit_pos[rec_idx];
+        const V3 over = mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]);  // fetched beside hit_pos, not after it
+        on = on && hp != NONE;
+        Rng rng;
+        rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+        if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
+        intensities<HAS_CSG, PER_LANE>(S, A, on, rec_idx, over, rng, flops, err, n_shadow);
     }
-    }  // records
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
@@ -1902,6 +1934,13 @@ struct FirstLevel {   // where the first level's rays come from
     const unsigned long long* seeds; // device: per global row (primary) or per ray; area lights only
 };
 
+// k_trace casts the shadow rays itself unless an area light needs the chunk's rng order first.
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
+void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
+    if (s->has_area) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+}
+
 // Queue every kernel of one batch of first-level rays on the workspace's stream: the levels, the
 // shadow rays, then the colours from the deepest level up (level 0 writes the outputs).  Nothing
 // here waits for the GPU unless the scene has an area light (its rng order needs the level sizes
@@ -1929,9 +1968,9 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         A.level = level;
         A.depth_remaining = depth - level;
         if (first.primary && level == 0)
-            hipLaunchKernelGGL((k_trace<true, HAS_CSG, PER_LANE>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+            launch_trace<true, HAS_CSG, PER_LANE>(s, grid, st, A);
         else
-            hipLaunchKernelGGL((k_trace<false, HAS_CSG, PER_LANE>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+            launch_trace<false, HAS_CSG, PER_LANE>(s, grid, st, A);
     }
     tot.trace_launches += n_levels;
     HIP_TRY(hipGetLastError());
@@ -1980,7 +2019,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         }
     }
 
-    hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
+    if (s->has_area) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
@@ -2155,7 +2194,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     }
     unit_of[d->n_nodes] = units;
     std::vector<uint32_t> stream((size_t)(units + 4) * 16, 0);  // padded: the walk may read one record ahead
-    std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0), cull((size_t)d->n_leaves * 6, 0.0);
+    std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0), cull((size_t)(units + 4) * 6, 0.0);
     auto inside_csg = [&](uint32_t node) {
         for (uint32_t j = 0; j < node; j++)
             if (d->node_kind[j] == RT_NODE_CSG && d->node_skip[j] > node) return true;
@@ -2194,7 +2233,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 for (int k = 0; k < 12; k++) recd[2 + k] = inv[k];
                 recd[14] = d->leaf_param[(size_t)leaf * 3 + 0];
                 recd[15] = d->leaf_param[(size_t)leaf * 3 + 1];
-                if (bounding_sphere(shape, inv, recd[14], recd[15], &cull[(size_t)leaf * 6])) {
+                if (bounding_sphere(shape, inv, recd[14], recd[15], &cull[(size_t)unit_of[i] * 6])) {
                     rec[0] |= 1u << 10;
                     // a sphere or cube outside any csg is always entered and left: wholly behind the
                     // origin it toggles the container list twice, i.e. not at all
@@ -2436,6 +2475,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->flop_trace = tot.flop_trace;
         stats->flop_shadow = tot.flop_shadow;
         stats->flop_light = tot.flop_light;
+        stats->fused_shadows = s->has_area ? 0 : 1;
     }
     return RT_OK;
 }
