@@ -127,6 +127,7 @@ struct Ray { V3 o, d; };
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
+    uint32_t n_materials, n_patterns;
     uint32_t flags;             // bit0: some material has a nonzero transparency
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
@@ -1338,7 +1339,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     }
 
     PHASE(7);
-#ifdef RT_PHASE_TIMERS
+#if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
     if (lane == 0)
         for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
 #endif
@@ -1423,9 +1424,46 @@ __device__ __noinline__ double shade_pow(double x, double y) { return pow(x, y);
 // (pattern/mod.rs:83-87), plus the colours of the spawned rays (world.rs:72-86,144,176).  No tree
 // walk here, so the register-hungry pow() stays out of the walking kernels' allocation.  Level 0
 // writes the frame buffers instead of the record.
+// With TABLES_IN_LDS every block first copies the scene's small tables (materials, pattern nodes,
+// the node stream) into LDS: the per-lane lookups hit-leaf -> material -> pattern node -> child
+// node are a chain of dependent gathers, and from LDS each link costs ~100 cycles instead of a
+// round trip to the L2.  Scenes whose tables do not fit keep reading them from memory.
+constexpr uint32_t SHADE_LDS_DOUBLES = 5120;  // 40 KB
+struct ShadeTables { uint32_t mat, pat_inv, pat_col, pat_meta, stream, total; };  // offsets in doubles
+__host__ __device__ inline ShadeTables shade_tables(uint32_t n_mat, uint32_t n_pat, uint32_t n_units) {
+    ShadeTables t;
+    t.mat = 0;
+    t.pat_inv = t.mat + n_mat * 8;
+    t.pat_col = t.pat_inv + n_pat * 12;
+    t.pat_meta = t.pat_col + n_pat * 4;
+    t.stream = t.pat_meta + (n_pat * 4 + 1) / 2;
+    t.total = t.stream + (n_units + 2) * 8;
+    return t;
+}
+
+template <bool TABLES_IN_LDS>
 __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArgs A) {
     if (A.counters->error & 1u) return;
     const LevelState lv = A.levels[A.level];
+    __shared__ double s_tab[TABLES_IN_LDS ? SHADE_LDS_DOUBLES : 1];
+    const double* t_mat = S.mat;
+    const uint32_t* t_stream = S.stream;
+    PatTables pt;
+    pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+    if constexpr (TABLES_IN_LDS) {
+        const ShadeTables T = shade_tables(S.n_materials, S.n_patterns, S.n_units);
+        for (uint32_t k = threadIdx.x; k < S.n_materials * 8; k += 256) s_tab[T.mat + k] = S.mat[k];
+        for (uint32_t k = threadIdx.x; k < S.n_patterns * 12; k += 256) s_tab[T.pat_inv + k] = S.pat_inv[k];
+        for (uint32_t k = threadIdx.x; k < S.n_patterns * 4; k += 256) s_tab[T.pat_col + k] = S.pat_col[k];
+        uint32_t* meta = (uint32_t*)(s_tab + T.pat_meta);
+        for (uint32_t k = threadIdx.x; k < S.n_patterns * 4; k += 256) meta[k] = S.pat_meta[k];
+        const double* sd = (const double*)S.stream;
+        for (uint32_t k = threadIdx.x; k < S.n_units * 8; k += 256) s_tab[T.stream + k] = sd[k];
+        __syncthreads();
+        t_mat = s_tab + T.mat;
+        t_stream = (const uint32_t*)(s_tab + T.stream);
+        pt.pat_meta = meta; pt.pat_inv = s_tab + T.pat_inv; pt.pat_col = s_tab + T.pat_col;
+    }
     uint32_t flops_sum = 0;
     for (uint32_t first = blockIdx.x * 256; first < lv.n; first += gridDim.x * 256) {
     LOOP_FENCE();
@@ -1438,17 +1476,23 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
     const V3 over = mk(A.R.px[rec], A.R.py[rec], A.R.pz[rec]), normal = mk(A.R.nx[rec], A.R.ny[rec], A.R.nz[rec]);
     const V3 eye = -mk(A.R.dx[rec], A.R.dy[rec], A.R.dz[rec]);
     const uint32_t cr_raw = A.R.child_refl[rec], ct_raw = A.R.child_refr[rec];
+#ifdef RT_PHASE_TIMERS
+    unsigned long long phase_t[8];
+    phase_t[0] = __builtin_readcyclecounter();
+    for (int k = 1; k < 8; k++) phase_t[k] = phase_t[0];
+#endif
+    PHASE(1);
     uint32_t flops = 0;
     V3 colour = mk(0.0, 0.0, 0.0);
     if (hit_pos != NONE) {
         const uint32_t cr = cr_raw, ct = ct_raw;
-        const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
+        const double* mat_rec = t_mat + (size_t)t_stream[(size_t)hit_pos * 16 + 1] * 8;
         const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
         const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
-        V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
-        PatTables pt;
-        pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+        V3 object_point = mul_point_v(leaf_inverse(t_stream, S.xform, hit_pos), over);
+        PHASE(2);
         const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
+        PHASE(3);
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states) rng = A.rng_states[A.R.order[rec]];
@@ -1495,6 +1539,7 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
             surface = surface + (ambient + ((diffuse + specular) / (double)samples) * intensity);
             flops += F_LIGHT * samples;
         }
+        PHASE(4);
         // shade_hit's sum (world.rs:72-86); a ray that was not spawned contributes black
         V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
         if (cr != NONE) reflected = mk(A.R.r[cr], A.R.g[cr], A.R.b[cr]) * m_reflective;
@@ -1508,6 +1553,7 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
             flops += F_COMBINE;
         }
     }
+    PHASE(5);
     if (on) {
         if (A.out_rgb || A.out_rgb8) {
             if (A.out_rgb) {
@@ -1522,6 +1568,13 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
             A.R.r[rec] = colour.x; A.R.g[rec] = colour.y; A.R.b[rec] = colour.z;
         }
     }
+    PHASE(6);
+#ifdef RT_PHASE_TIMERS
+#ifdef RT_PHASE_SHADE
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
+#endif
+#endif
     flops_sum += flops;
     }  // records
     const uint32_t flops = flops_sum;
@@ -1855,6 +1908,7 @@ struct rt_scene {
     DevScene dev{};
     std::vector<void*> allocations;
     bool has_csg = false, has_area = false;
+    bool shade_lds = false;             // the tables k_shade looks things up in fit in LDS
     int device = 0;
     Workspace ws[MAX_STREAMS];
     int n_streams = 2;
@@ -2024,7 +2078,8 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
         if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
-        hipLaunchKernelGGL(k_shade, grid, block, 0, st, s->dev, A);
+        if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
+        else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, st, s->dev, A);
     }
     HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
     hipLaunchKernelGGL(k_chunk_end, dim3(1), dim3(STAT_SHARDS), 0, st, w.levels, n_levels, w.counters, w.stats,
@@ -2291,6 +2346,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         light_meta[(size_t)i * 4 + 2] = area ? d->light_steps[(size_t)i * 2 + 1] : 1;
     }
     s->dev.n_units = units; s->dev.n_lights = d->n_lights;
+    s->dev.n_materials = d->n_materials; s->dev.n_patterns = d->n_patterns;
+    s->shade_lds = shade_tables(d->n_materials, d->n_patterns, units).total <= SHADE_LDS_DOUBLES;
     s->dev.class_words = (uint32_t)words;
     s->dev.draws_per_shade = (uint32_t)draws;
     s->dev.flags = 0;
