@@ -1486,6 +1486,11 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
     V3 colour = mk(0.0, 0.0, 0.0);
     if (hit_pos != NONE) {
         const uint32_t cr = cr_raw, ct = ct_raw;
+        // the spawned rays' colours are a scattered read from the level below: requested now,
+        // needed only after the lighting
+        V3 child_r = mk(0.0, 0.0, 0.0), child_t = mk(0.0, 0.0, 0.0);
+        if (cr != NONE) child_r = mk(A.R.r[cr], A.R.g[cr], A.R.b[cr]);
+        if (ct != NONE) child_t = mk(A.R.r[ct], A.R.g[ct], A.R.b[ct]);
         const double* mat_rec = t_mat + (size_t)t_stream[(size_t)hit_pos * 16 + 1] * 8;
         const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
         const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
@@ -1542,8 +1547,8 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         PHASE(4);
         // shade_hit's sum (world.rs:72-86); a ray that was not spawned contributes black
         V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
-        if (cr != NONE) reflected = mk(A.R.r[cr], A.R.g[cr], A.R.b[cr]) * m_reflective;
-        if (ct != NONE) refracted = mk(A.R.r[ct], A.R.g[ct], A.R.b[ct]) * m_transparency;
+        if (cr != NONE) reflected = child_r * m_reflective;
+        if (ct != NONE) refracted = child_t * m_transparency;
         if (m_reflective > 0.0 && m_transparency > 0.0) {
             const double Rf = A.R.reflectance[rec];
             colour = surface + reflected * Rf + refracted * (1.0 - Rf);
