@@ -354,6 +354,7 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
 struct Walk {
     double t;              // closest hit so far
     uint32_t pos;          // unit position of the hit leaf's record, or NONE
+    uint32_t w0, mat, cls; // of that leaf: header word 0 (shape, casts_shadow, closed), material, class
     uint32_t arrival;      // intersections seen (the length of the reference's list)
     bool nan_seen;
     int n;                 // recorded candidates
@@ -361,7 +362,7 @@ struct Walk {
 };
 DEV Walk walk_init() {
     Walk w;
-    w.t = 0.0; w.pos = NONE; w.arrival = 0; w.nan_seen = false; w.n = 0; w.overflow = false;
+    w.t = 0.0; w.pos = NONE; w.w0 = 0; w.mat = 0; w.cls = 0; w.arrival = 0; w.nan_seen = false; w.n = 0; w.overflow = false;
     return w;
 }
 
@@ -426,7 +427,10 @@ DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uin
             if (left_hit) in_left = !in_left; else in_right = !in_right;
         }
         if (cs_top == 0) {
-            for (int a = start; a < wr; a++) emit(true, ct[a], cl[a], want_class ? S.stream[(size_t)cl[a] * 16 + 3] : 0u);
+            for (int a = start; a < wr; a++) {
+                const uint32_t* lr = S.stream + (size_t)cl[a] * 16;
+                emit(true, ct[a], cl[a], lr[3], lr[0], lr[1]);
+            }
             clen = start;
         } else {
             clen = wr;
@@ -454,7 +458,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
 
     // `cls` is the structural-equality class of the leaf at unit position p
-    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t lmat) {
         if (on) {
             if (tt != tt) w.nan_seen = true;
             const bool below = w.pos == NONE || tt < w.t;
@@ -463,7 +467,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                     if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
                 }
             }
-            if (tt > 0.0 && below) { w.t = tt; w.pos = p; }
+            if (tt > 0.0 && below) { w.t = tt; w.pos = p; w.w0 = lw0; w.mat = lmat; w.cls = cls; }
             w.arrival++;
         }
     };
@@ -580,7 +584,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                     on = false;
                 }
             }
-            emit(on, h.t[k], i, w3);
+            emit(on, h.t[k], i, w3, w0, w1);
         }
         i += 2;
     }
@@ -600,7 +604,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
     int cs_start[HAS_CSG ? CSG_DEPTH : 1];
     int clen = 0, cs_top = 0;
     (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
-    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t lmat) {
         if (on) {
             if (tt != tt) w.nan_seen = true;
             const bool below = w.pos == NONE || tt < w.t;
@@ -609,7 +613,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                     if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
                 }
             }
-            if (tt > 0.0 && below) { w.t = tt; w.pos = p; }
+            if (tt > 0.0 && below) { w.t = tt; w.pos = p; w.w0 = lw0; w.mat = lmat; w.cls = cls; }
             w.arrival++;
         }
     };
@@ -693,7 +697,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                             on = false;
                         }
                     }
-                    emit(on, h.t[k], i, w3);
+                    emit(on, h.t[k], i, w3, w0, w1);
                 }
             }
             i += 2;
@@ -1159,10 +1163,7 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             walk_tree<HAS_CSG, true, PER_LANE>(S, sr, on, false, w, NoRecord{}, flops, true, err);
             if (w.nan_seen && w.arrival >= 2) err |= 4u;
             bool shadowed = false;
-            if (on && w.pos != NONE) {
-                bool casts = (S.stream[(size_t)w.pos * 16] >> 8) & 1u;
-                shadowed = casts && w.t < distance;
-            }
+            if (on && w.pos != NONE) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
             if (!shadowed) unshadowed += 1.0;
             if (on) { flops += F_SHADOW; n_shadow++; }
         }
@@ -1240,8 +1241,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     const bool hit = on && w.pos != NONE;
     const double hit_t = w.t;
     const uint32_t hit_pos = w.pos;
-    const uint32_t hit_cls = hit ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
-    const double* mat_rec = S.mat + (hit ? (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8 : 0);
+    const uint32_t hit_cls = w.cls;
+    const double* mat_rec = S.mat + (hit ? (size_t)w.mat * 8 : 0);
     const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
     PHASE(3);
     // for refractive hits: n1, n2 from the intersections that sort before the hit
