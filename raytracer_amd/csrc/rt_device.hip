@@ -1340,10 +1340,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     }
 
     PHASE(7);
-#if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
-    if (lane == 0)
-        for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
-#endif
     n_spawned += n_refl + n_refr;  // wave-uniform
     if (hit) n_shade++;
     // the shadow rays of this hit, unless the lights need the chunk's rng order first (k_shadow):
@@ -1353,6 +1349,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
         intensities<HAS_CSG, PER_LANE>(S, A, hit, rec_idx, over, none, flops_shadow, err, n_shadow);
     }
+#if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
+    {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long t_end = __builtin_readcyclecounter();
+        if (lane == 0) {
+            for (int k = 1; k < 8; k++) atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[k], phase_t[k] - phase_t[k - 1]);
+            atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].phase[0], t_end - phase_t[7]);
+        }
+    }
+#endif
     }  // steps
 
     // statistics: one atomic per wave and counter
@@ -2145,8 +2151,8 @@ void print_phases(Workspace& w) {
     (void)hipMemset(w.stats, 0, STAT_SHARDS * sizeof(StatShard));
     unsigned long long ph[8] = {0};
     for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
-    static const char* names[8] = {"", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
-    for (int k = 1; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
+    static const char* names[8] = {"shadows", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
+    for (int k = 0; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
 }
 #endif
 
