@@ -207,7 +207,8 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  * Tuning knobs of a scene's renderer (no counterpart in the reference; the
  * defaults suit a 288 GB MI355X).  Results do not depend on them.
  *   RT_OPT_STREAMS         1 or 2: image-row chunks in flight at once (default 2)
- *   RT_OPT_CHUNK_PIXELS    pixels per chunk (default 4 Mi); a chunk is whole rows,
+ *   RT_OPT_CHUNK_PIXELS    pixels per chunk (default 16 Mi, and at least four chunks
+ *                          for a frame of a megapixel or more); a chunk is whole rows,
  *                          a multiple of 8 of them
  *   RT_OPT_RECS_PER_PIXEL  ray records reserved per pixel of a chunk (default
  *                          24); a chunk that needs more is split and retried

@@ -1929,7 +1929,7 @@ struct rt_scene {
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
-    size_t chunk_pixels = (size_t)4 << 20;
+    size_t chunk_pixels = (size_t)16 << 20;
     size_t recs_per_pixel = 24;
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
@@ -2461,6 +2461,12 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     // pending chunk (alternating over the workspaces so two chunks overlap on the GPU), then
     // waits; chunks whose rays did not fit their record arrays are split and go round again.
     uint32_t chunk_rows = (uint32_t)std::max<size_t>(8, (s->chunk_pixels / W) & ~(size_t)7);
+    if ((size_t)rows * W >= ((size_t)1 << 20)) {
+        // at least four chunks for a frame of a megapixel or more, so that both streams stay busy
+        // (a rank of a multi-GPU job only renders its share of the rows)
+        uint32_t quarter = ((rows + 3) / 4 + 7) & ~7u;
+        chunk_rows = std::max(8u, std::min(chunk_rows, quarter));
+    }
     struct Job { uint32_t r0, nr; };
     std::vector<Job> pending;
     for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0)});
