@@ -987,7 +987,7 @@ DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, i
 // early: it and everything after it in sorted order drop out.  `need` is false for lanes that only
 // keep the wave company.
 DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf cb, int n, bool need, double hit_t,
-                             uint32_t hit_pos, uint32_t hit_cls) {
+                             uint32_t hit_pos, uint32_t hit_cls, bool few_classes) {
     constexpr int N = REC_CAP;
     const int S = cb.stride;
     // the longest list of the wave bounds every loop below (wave-uniform, so the unrolled
@@ -1032,23 +1032,34 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
         }
     }
     bool cand[N];
+    if (few_classes) {
+        // class ids fit a 64-bit set: one pass for the parities, and an entry is a candidate iff
+        // its class has odd parity (the greatest key among them is necessarily its class's latest)
+        unsigned long long parity = 0ull;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        cand[i] = false;
-        if (i < nmax) {
-            bool odd = false, last = true;
+        for (int i = 0; i < N; i++)
+            if (i < nmax && v[i]) parity ^= 1ull << (c[i] & 63u);
 #pragma unroll
-            for (int j = 0; j < N; j++) {
-                if (j < nmax) {
-                    bool same = v[j] && c[j] == c[i];
-                    odd = odd != same;
-                    if (j != i) {
-                        bool later = j > i ? t[j] >= t[i] : t[j] > t[i];
-                        if (same && later) last = false;
+        for (int i = 0; i < N; i++) cand[i] = i < nmax && v[i] && ((parity >> (c[i] & 63u)) & 1ull);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            cand[i] = false;
+            if (i < nmax) {
+                bool odd = false, last = true;
+#pragma unroll
+                for (int j = 0; j < N; j++) {
+                    if (j < nmax) {
+                        bool same = v[j] && c[j] == c[i];
+                        odd = odd != same;
+                        if (j != i) {
+                            bool later = j > i ? t[j] >= t[i] : t[j] > t[i];
+                            if (same && later) last = false;
+                        }
                     }
                 }
+                cand[i] = v[i] && odd && last;
             }
-            cand[i] = v[i] && odd && last;
         }
     }
     bool have1 = false, have2 = false, hit_present = false;
@@ -1250,7 +1261,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     const bool need_cont = hit && (!approx0(m_transparency) || m_transparency > 0.0);
     if (__ballot(need_cont) != 0ull) {
         const bool small = need_cont && w.n <= REC_CAP;
-        N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls);
+        N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls, S.class_words <= 1);
         if (need_cont && !small) {  // rare: continue in the lane-private buffer
             if (w.overflow) err |= 2u;
             for (int k = 0; k < REC_CAP; k++)
@@ -1745,7 +1756,7 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
             if (__ballot(need) != 0ull) {  // n1 / n2 from the recorded candidates
                 const uint32_t hit_cls = need ? S.stream[(size_t)hit_pos * 16 + 3] : 0u;
                 const bool small = need && w.n <= REC_CAP;
-                N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls);
+                N1N2 nn = container_walk_regs(S.stream, S.mat, buf.fast, w.n, small, hit_t, hit_pos, hit_cls, S.class_words <= 1);
                 if (need && !small) {
                     if (w.overflow) err |= 2u;
                     for (int k = 0; k < REC_CAP; k++)
