@@ -1008,13 +1008,17 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
         }
     }
     // early end of the walk (rare): the first entry in sorted order that equals the hit
+    // (a cheap superset of approx_eq first: 4 ulps or f64::EPSILON are below 1e-15 relative + 3e-16)
     bool m[N], any_m = false;
+    const double near = fabs(hit_t) * 1e-15 + 3e-16;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         m[k] = false;
-        if (k < nmax) { m[k] = v[k] && c[k] == hit_cls && approx_eq(t[k], hit_t); any_m = any_m || m[k]; }
+        if (k < nmax) { m[k] = v[k] && c[k] == hit_cls && hit_t - t[k] <= near; any_m = any_m || m[k]; }
     }
     if (__ballot(any_m) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < N; k++) m[k] = m[k] && approx_eq(t[k], hit_t);
         bool have = false;
         double st = 0.0;
 #pragma unroll
