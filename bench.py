@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=768, help="rows of the frame the CPU oracle renders for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1 or 2)")
+    ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1..4)")
     ap.add_argument("--grid-blocks", type=int, default=None)
     ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane")
     ap.add_argument("--chunk-pixels", type=int, default=None)

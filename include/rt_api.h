@@ -143,7 +143,8 @@ typedef struct rt_stats {
                                 with two streams the chunks overlap, so the three
                                 sums can exceed ms_total                           */
     double ms_shadow;        /* the same for k_shadow (shadow rays, one per chunk;
-                                only launched for scenes with an area light)       */
+                                only launched for scenes with an area light or a
+                                tree that is walked lane by lane)                  */
     double ms_shade;         /* the same for the k_shade launches (patterns + Phong
                                 + the sum with the spawned rays' colours)          */
     uint64_t trace_launches; /* number of k_trace launches                         */
@@ -153,7 +154,7 @@ typedef struct rt_stats {
     uint64_t flop_shadow;    /* shadow-ray walks (inside k_trace when fused_shadows) */
     uint64_t flop_light;
     uint64_t fused_shadows;  /* 1: k_trace cast the shadow rays itself and ms_shadow
-                                is 0; 0: k_shadow did (scenes with an area light)  */
+                                is 0; 0: k_shadow did (area lights, meshes)        */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

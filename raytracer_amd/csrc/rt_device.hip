@@ -626,11 +626,18 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
         if (__ballot(act) == 0ull) break;
         const uint32_t* rec = S.stream + (size_t)(act ? i : 0u) * 16;
         const double* recd = (const double*)rec;
-        const uint32_t w0 = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3];
+        // the node's first unit in one batch of loads (header and box of a group, header and the
+        // start of a leaf's data): a group then costs one memory round trip, not two in a row
+        double u0[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) u0[k] = recd[k];
+        asm volatile("" ::"v"(u0[0]), "v"(u0[1]), "v"(u0[2]), "v"(u0[3]), "v"(u0[4]), "v"(u0[5]), "v"(u0[6]), "v"(u0[7]));
+        const uint32_t w0 = (uint32_t)__double2loint(u0[0]), w1 = (uint32_t)__double2hiint(u0[0]);
+        const uint32_t w2 = (uint32_t)__double2loint(u0[1]), w3 = (uint32_t)__double2hiint(u0[1]);
         const uint32_t kind = w0 & 0xFFu;
         if (act && kind >= K_GROUP) {
             double t0, t1;
-            bool hit = box_intersect(ray, recd[2], recd[3], recd[4], recd[5], recd[6], recd[7], t0, t1);
+            bool hit = box_intersect(ray, u0[2], u0[3], u0[4], u0[5], u0[6], u0[7], t0, t1);
             if (count) flops += F_BOX;
             if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             uint32_t next = hit ? i + 1 : w1;
@@ -666,14 +673,14 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                 h.n = 0;
                 uint32_t f = F_XFORM;
                 if (kind == RT_TRIANGLE) {
-                    const uint32_t xf = rec[4];
+                    const uint32_t xf = (uint32_t)__double2loint(u0[2]);
                     if (xf != cur_xform) {
                         cur_xform = xf;
                         const double* m = S.xform + (size_t)xf * 12;
                         tri_ray.o = mul_point_v(m, ray.o);
                         tri_ray.d = mul_vector_v(m, ray.d);
                     }
-                    V3 p1 = mk(recd[4], recd[5], recd[6]), e1 = mk(recd[7], recd[8], recd[9]), e2 = mk(recd[10], recd[11], recd[12]);
+                    V3 p1 = mk(u0[4], u0[5], u0[6]), e1 = mk(u0[7], recd[8], recd[9]), e2 = mk(recd[10], recd[11], recd[12]);
                     double t, u, v;
                     if (triangle_hit(tri_ray, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
                     f += F_TRI;
@@ -1928,7 +1935,7 @@ struct Workspace {
     uint32_t *row_total = nullptr, *row_base = nullptr;
     size_t row_cap = 0, row_base_cap = 0;
 };
-constexpr int MAX_STREAMS = 2;
+constexpr int MAX_STREAMS = 4;
 constexpr uint32_t PER_LANE_MIN_UNITS = 512;  // trees above this many 64-byte units are walked lane by lane
 
 struct rt_scene {
@@ -2015,11 +2022,16 @@ struct FirstLevel {   // where the first level's rays come from
     const unsigned long long* seeds; // device: per global row (primary) or per ray; area lights only
 };
 
-// k_trace casts the shadow rays itself unless an area light needs the chunk's rng order first.
+// k_trace casts the shadow rays itself unless an area light needs the chunk's rng order first, or
+// the tree is walked lane by lane: there the deep levels hold few rays with long walks, and a
+// shadow walk behind each of them doubles the serial chain, while k_shadow runs all the chunk's
+// shadow rays side by side.
+bool uses_lane_walk(const rt_scene* s) { return s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS); }
+bool fused_shadows(const rt_scene* s, bool per_lane) { return !s->has_area && !per_lane; }
 template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
 void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
-    if (s->has_area) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
-    else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    if (fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
 }
 
 // Queue every kernel of one batch of first-level rays on the workspace's stream: the levels, the
@@ -2100,7 +2112,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         }
     }
 
-    if (s->has_area) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
+    if (!fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
@@ -2117,7 +2129,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
 
 int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
                          double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
-    const bool per_lane = s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS);
+    const bool per_lane = uses_lane_walk(s);
     if (s->has_csg) {
         if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
         return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
@@ -2402,7 +2414,7 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
     if (!s) return fail(RT_ERR_INVALID, "null argument");
     switch (option) {
         case RT_OPT_STREAMS:
-            if (value < 1 || value > MAX_STREAMS) return fail(RT_ERR_INVALID, "streams must be 1 or 2");
+            if (value < 1 || value > MAX_STREAMS) return fail(RT_ERR_INVALID, "streams must be 1..4");
             s->n_streams = (int)value;
             return RT_OK;
         case RT_OPT_CHUNK_PIXELS:
@@ -2565,7 +2577,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->flop_trace = tot.flop_trace;
         stats->flop_shadow = tot.flop_shadow;
         stats->flop_light = tot.flop_light;
-        stats->fused_shadows = s->has_area ? 0 : 1;
+        stats->fused_shadows = fused_shadows(s, uses_lane_walk(s)) ? 1 : 0;
     }
     return RT_OK;
 }

@@ -133,7 +133,7 @@ def test_tuning_options_do_not_change_the_image(scene, depth):
         if ra.OPT_CHUNK_PIXELS in opts:
             assert st["chunks"] > 1
     with pytest.raises(ra.RtError):
-        g.set_option(ra.OPT_STREAMS, 3)
+        g.set_option(ra.OPT_STREAMS, 5)
 
 
 def test_full_size_headline_frame_properties():
