@@ -534,13 +534,14 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             // that are always entered and left) it lies wholly behind the origin.  Such intersections
             // can neither become the hit nor sort before it, so the test is skipped for the wave.
             const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
-            const double r = cs[3], r2 = cs[4];
+            const double r2 = cs[4];
             const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
             const bool outside = cc > r2;
             const bool miss = outside && b * b < dd * (cc - r2);
             const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
-            // entry parameter >= b/dd - r/|d|, and |d| <= |dx| + |dy| + |dz|
-            const bool beyond = w.pos != NONE && b - r * (fabs(ray.d.x) + fabs(ray.d.y) + fabs(ray.d.z)) > (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+            // entry parameter >= b/dd - r/|d|: beyond the hit so far iff b - t*dd > r*|d|, squared to avoid |d|
+            const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+            const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
             if (__ballot(act && !(miss || behind || beyond)) == 0ull) {
                 // the reference would have run the test: it still counts as algorithmic work
                 if (act && count)
@@ -658,12 +659,13 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             if (CULL && (w0 & (1u << 10))) {  // see the wave-uniform walk
                 const double* cs = S.cull + (size_t)i * 6;
                 const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
-                const double r = cs[3], r2 = cs[4];
+                const double r2 = cs[4];
                 const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
                 const bool outside = cc > r2;
                 const bool miss = outside && b * b < dd * (cc - r2);
                 const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
-                const bool beyond = w.pos != NONE && b - r * (fabs(ray.d.x) + fabs(ray.d.y) + fabs(ray.d.z)) > (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+                const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+                const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
                 culled = miss || behind || beyond;
                 if (culled && count)
                     flops += F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE);
