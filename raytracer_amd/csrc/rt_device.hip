@@ -1,30 +1,36 @@
 // MI355X (gfx950) rendering core: the device side of include/rt_api.h.
 //
-// One launch per recursion level.  A level kernel takes one ray per lane
-// (level 0 builds it from the pixel, deeper levels read a ray queue) and runs
-// a short list of "jobs" through ONE copy of the tree walk: closest hit of the
-// ray, (for refractive hits) the intersections that precede the hit, then one
-// shadow ray per light sample.  The walk is a wavefront walk: the position in
-// the node stream is wave-uniform and only grows, each node record arrives
-// with one burst of scalar loads (so transforms and boxes sit in SGPRs), and
-// each lane carries a "skip until" position for the subtrees its own box tests
-// rejected.  The closest hit stays in registers.  The lane then writes one
-// 64-byte node record and appends the reflected / refracted rays to the next
-// level's queue with one atomic per wave.  After the last level a bottom-up
-// pass folds the records into colours with exactly the association order of
-// the recursive reference:
-//   surface + reflected * reflectance + refracted * (1 - reflectance).
+// The recursion of World::colour_at becomes level-synchronous waves of rays.  A frame is cut into
+// chunks of whole image rows; for each chunk the host queues, without waiting for the GPU,
+//   k_chunk_begin, one k_trace per recursion level, [k_shadow], one k_shade per level from the
+//   deepest up, k_chunk_end,
+// on one of a few streams (chunks alternate over them, each with its own workspace).  How many
+// rays a level holds lives in device memory (LevelState), so every kernel is a fixed grid whose
+// blocks stride over the level's rays.
 //
-// Scenes with area lights take a deferred route, because the reference threads
-// one rng stream through a whole image row in depth-first order: the level
-// kernels only trace (ray paths never depend on the rng), a few small passes
-// number the shade points of each row in the reference's order and step the
-// row's generator to each of them, then one kernel shades every point with
-// its own generator state.
+//   k_trace  one ray per lane: closest hit (tree walk), n1/n2 for refractive hits, the hit's
+//            geometry, the reflected / refracted rays appended to the next level (one atomic per
+//            block), the hit record, and - unless an area light or a lane-walked tree forbids
+//            it - one shadow walk per light.
+//   k_shade  pattern, Material::lighting and
+//              surface + reflected * reflectance + refracted * (1 - reflectance)
+//            with exactly the association order of the recursive reference; level 0 writes the
+//            frame buffers.
 //
-// All arithmetic is f64 with contraction off; expressions keep the operand
-// order of the reference (cited per function, paths relative to the
-// reference's src/).
+// The tree is a depth-first stream of 64-byte units with skip links.  Small trees are walked by
+// the 64 lanes of a wave together (position in an SGPR, node data through scalar loads, a
+// per-lane "skip until" for rejected subtrees); large ones (meshes) lane by lane.  Intersections
+// arrive in the reference's insertion order, so a strict `<` against the running best reproduces
+// its stable sort + first-positive-t rule without sorting.
+//
+// Scenes with area lights take a deferred route, because the reference threads one rng stream
+// through a whole image row in depth-first order: the level kernels only trace (ray paths never
+// depend on the rng), a few small passes number the shade points of each row in the reference's
+// order and step the row's generator to each of them, then k_shadow and k_shade give every
+// point its own generator state.
+//
+// All arithmetic is f64 with contraction off; expressions keep the operand order of the
+// reference (cited per function, paths relative to the reference's src/).
 
 #include <hip/hip_runtime.h>
 
@@ -63,7 +69,7 @@ constexpr int WAVE = 64;
 #define SHADE_WAVES 3     // and for k_shade
 #endif
 #ifndef TRACE_BLOCK
-#define TRACE_BLOCK 256   // threads per k_trace block: one queue-append atomic per block
+#define TRACE_BLOCK 256   // threads per k_trace block: one append atomic per block and step
 #endif
 #ifndef REC_CAP
 #define REC_CAP 8         // candidates per lane recorded in LDS during the closest-hit walk (16 B each)
