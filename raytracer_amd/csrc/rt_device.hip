@@ -59,6 +59,10 @@ constexpr int CSG_DEPTH = 6;       // nested csg levels
 constexpr int CONT_CAP = 32;       // intersections at or before a refractive hit
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
+#ifndef FEW_RAYS_MAX
+#define FEW_RAYS_MAX 16384
+#endif
+constexpr uint32_t FEW_RAYS = FEW_RAYS_MAX;  // a level of a lane-walked tree with at most this many rays gets a wave per ray
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 4     // occupancy the compiler must reach for k_trace (waves per SIMD; csg variants: 2)
 #endif
@@ -163,6 +167,15 @@ DEV uint32_t wave_min_u32(uint32_t v) {
         v = o < v ? o : v;
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+DEV double wave_min_f64(double v) {  // no NaNs expected
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int lo = __shfl_xor(__double2loint(v), off, WAVE), hi = __shfl_xor(__double2hiint(v), off, WAVE);
+        double o = __hiloint2double(hi, lo);
+        v = o < v ? o : v;
+    }
+    return v;
 }
 DEV uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -449,7 +462,11 @@ DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uin
 // object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
 // change the closest hit or what sorts before it (w.arrival then no longer counts every
 // intersection of the reference's list; rt_probe, which reports that count, walks without it).
-template <bool HAS_CSG, bool CULL, class Buf>
+// With ONE_RAY all 64 lanes carry the same ray (levels with so few rays that a wave per ray is
+// affordable): everything is redundant across the lanes except runs of sibling triangles, which
+// are tested 64 at a time, one triangle per lane - a ray's walk through a mesh is a long serial
+// chain, and the runs are most of it.
+template <bool HAS_CSG, bool CULL, class Buf, bool ONE_RAY = false>
 DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
                   bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
@@ -564,6 +581,39 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             if (xf != cur_xform) {  // wave-uniform: one transform per mesh matrix
                 cur_xform = xf;
                 tri_ray = to_object_u(S.xform, xf * 12, ray);
+            }
+            if constexpr (ONE_RAY) {
+                bool in_csg = false;
+                if constexpr (HAS_CSG) in_csg = cs_top > 0;
+                if (!(Buf::enabled && record) && !in_csg) {
+                    // this triangle and the siblings that follow it (q[3] low word: how many), one per
+                    // lane.  In list order the running best ends as the smallest t among those that
+                    // beat it, the earliest on ties: a minimum over the lanes, lowest lane first.
+                    const uint32_t cnt = min((uint32_t)__double2loint(q[3]) + 1u, 64u);
+                    const uint32_t ln = threadIdx.x & 63u;
+                    const bool mine = act && ln < cnt;
+                    const uint32_t* lr = S.stream + (size_t)(i + 2u * (mine ? ln : 0u)) * 16;
+                    const double* ld = (const double*)lr;
+                    double t = 0.0, u, v;
+                    const bool got = mine && triangle_hit(tri_ray, mk(ld[4], ld[5], ld[6]), mk(ld[7], ld[8], ld[9]),
+                                                          mk(ld[10], ld[11], ld[12]), t, u, v);
+                    if (mine) flops += F_XFORM + F_TRI;
+                    if (__ballot(got && t != t) != 0ull) w.nan_seen = true;
+                    w.arrival += (uint32_t)__popcll(__ballot(got));
+                    const bool better = got && t > 0.0 && (w.pos == NONE || t < w.t);
+                    const double tmin = wave_min_f64(better ? t : __builtin_huge_val());
+                    const unsigned long long winners = __ballot(better && t == tmin);
+                    if (winners != 0ull) {
+                        const int win = __ffsll((long long)winners) - 1;
+                        w.t = tmin;
+                        w.pos = i + 2u * (uint32_t)win;
+                        w.w0 = (uint32_t)__shfl((int)lr[0], win, WAVE);
+                        w.mat = (uint32_t)__shfl((int)lr[1], win, WAVE);
+                        w.cls = (uint32_t)__shfl((int)lr[3], win, WAVE);
+                    }
+                    i += 2u * cnt;
+                    continue;
+                }
             }
             V3 p1 = mk(q[4], q[5], q[6]), e1 = mk(q[7], q[8], q[9]), e2 = mk(q[10], q[11], q[12]);
             double t, u, v;
@@ -1227,7 +1277,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
+    // a lane-walked tree and few rays: one wave per ray (see traverse<ONE_RAY>)
+    const bool few = PER_LANE && !PRIMARY && n_rays <= FEW_RAYS;
     const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
+                             : few   ? (n_rays + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
                                      : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
     uint32_t parity = 0;
     for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x, parity ^= 1u) {
@@ -1255,7 +1308,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
             A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
         }
     } else {
-        uint32_t idx = step * TRACE_BLOCK + threadIdx.x;
+        uint32_t idx = few ? step * (TRACE_BLOCK / 64) + wave_in_block : step * TRACE_BLOCK + threadIdx.x;
         on = idx < n_rays;
         rec_idx = rec_base + (on ? idx : 0);
         ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
@@ -1265,7 +1318,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
+    if constexpr (PER_LANE && !PRIMARY) {
+        if (few) {
+            traverse<HAS_CSG, true, RecordBuf, true>(S, ray, on, record, w, buf, flops, lane == 0, err);
+            on = on && lane == 0;  // one lane finishes the ray
+        } else {
+            walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
+        }
+    } else {
+        walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
+    }
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -2329,6 +2391,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 uint32_t tri = d->leaf_tri[leaf];
                 rec[4] = id;
                 rec[5] = tri;
+                rec[6] = 0;  // filled below: how many sibling triangles of the same mesh matrix follow directly
                 for (int k = 0; k < 9; k++) recd[4 + k] = d->tri_data[(size_t)tri * 18 + k];
                 for (int k = 0; k < 9; k++) tri_normals[(size_t)tri * 9 + k] = d->tri_data[(size_t)tri * 18 + 9 + k];
             } else {
@@ -2349,6 +2412,25 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rec[1] = unit_of[d->node_skip[i]];
             rec[2] = csg ? d->node_arg[i] : 0;
             for (int k = 0; k < 6; k++) recd[2 + k] = d->node_bbox[(size_t)i * 6 + k];
+        }
+    }
+
+    // runs of sibling triangles: node i+1 is the next sibling of leaf i exactly when it lies in the
+    // same parent, i.e. no enclosing subtree ends at i+1
+    {
+        std::vector<uint32_t> parent_end(d->n_nodes, d->n_nodes), stack_end;
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            while (!stack_end.empty() && stack_end.back() <= i) stack_end.pop_back();
+            parent_end[i] = stack_end.empty() ? d->n_nodes : stack_end.back();
+            if (d->node_kind[i] != RT_NODE_LEAF) stack_end.push_back(d->node_skip[i]);
+        }
+        for (uint32_t i = d->n_nodes; i-- > 0;) {
+            if (d->node_kind[i] != RT_NODE_LEAF || d->leaf_shape[d->node_arg[i]] != RT_TRIANGLE) continue;
+            uint32_t* rec = &stream[(size_t)unit_of[i] * 16];
+            uint32_t j = i + 1;
+            if (j < d->n_nodes && j < parent_end[i] && d->node_kind[j] == RT_NODE_LEAF &&
+                d->leaf_shape[d->node_arg[j]] == RT_TRIANGLE && stream[(size_t)unit_of[j] * 16 + 4] == rec[4])
+                rec[6] = stream[(size_t)unit_of[j] * 16 + 6] + 1;
         }
     }
 
