@@ -207,7 +207,7 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
 /*
  * Tuning knobs of a scene's renderer (no counterpart in the reference; the
  * defaults suit a 288 GB MI355X).  Results do not depend on them.
- *   RT_OPT_STREAMS         1 or 2: image-row chunks in flight at once (default 2)
+ *   RT_OPT_STREAMS         1..4: image-row chunks in flight at once (default 2)
  *   RT_OPT_CHUNK_PIXELS    pixels per chunk (default 16 Mi, and at least four chunks
  *                          for a frame of a megapixel or more); a chunk is whole rows,
  *                          a multiple of 8 of them
@@ -217,9 +217,11 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *   RT_OPT_TRAVERSAL       0: chosen by tree size (default); 1: the 64 lanes of a
  *                          wave walk the tree together; 2: every lane walks on
  *                          its own (large trees, meshes)
+ *   RT_OPT_MIN_CHUNKS      a frame of a megapixel or more is cut into at least this
+ *                          many chunks (default 4)
  */
 enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4,
-       RT_OPT_TRAVERSAL = 5 };
+       RT_OPT_TRAVERSAL = 5, RT_OPT_MIN_CHUNKS = 6 };
 int rt_set_option(rt_scene *scene, int option, uint64_t value);
 
 /* Limits of this build (per-ray list bounds). */

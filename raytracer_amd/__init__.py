@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
 )
-OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL = 1, 2, 3, 4, 5
+OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS = 1, 2, 3, 4, 5, 6
 HOST_ABI_SYMBOLS = (
     "rth_last_error", "rth_scene_from_file", "rth_scene_from_text", "rth_scene_spheres", "rth_scene_free",
     "rth_scene_info", "rth_scene_desc", "rth_camera", "rth_camera_nudge_half_view", "rth_row_seeds", "rth_upload",

@@ -1215,8 +1215,8 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // light/area.rs:75-90): one closest-hit shadow ray per light sample (World::is_shadowed,
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
 template <bool HAS_CSG, bool PER_LANE>
-DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, Rng rng, uint32_t& flops,
-                     uint32_t& err, uint32_t& n_shadow) {
+DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
+                     uint32_t& flops, uint32_t& err, uint32_t& n_shadow) {
     if (__ballot(on) == 0ull) return;
     for (uint32_t l = 0; l < S.n_lights; l++) {
         const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
@@ -1239,11 +1239,18 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             Ray sr;
             sr.o = over;
             sr.d = normalise(vec);
+            // A point light behind the surface: Material::lighting takes neither diffuse nor specular
+            // from it (light_dot_normal < 0, material.rs:70-83, the same expression as in k_shade), so
+            // whatever is_shadowed answers is multiplied by zero.  The ray still counts as cast.
+            const bool moot = !is_area && dot(sr.d, normal) < 0.0;
+            const bool cast = on && !moot;
             Walk w = walk_init();
-            walk_tree<HAS_CSG, true, PER_LANE>(S, sr, on, false, w, NoRecord{}, flops, true, err);
-            if (w.nan_seen && w.arrival >= 2) err |= 4u;
-            bool shadowed = false;
-            if (on && w.pos != NONE) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
+            if (__ballot(cast) != 0ull) {
+                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, cast, false, w, NoRecord{}, flops, true, err);
+                if (w.nan_seen && w.arrival >= 2) err |= 4u;
+            }
+            bool shadowed = moot;  // reported as intensity 0: k_shade then skips the light's loop as well
+            if (cast && w.pos != NONE) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
             if (!shadowed) unshadowed += 1.0;
             if (on) { flops += F_SHADOW; n_shadow++; }
         }
@@ -1439,7 +1446,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     if constexpr (SHADOWS) {
         Rng none;
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE>(S, A, hit, rec_idx, over, none, flops_shadow, err, n_shadow);
+        intensities<HAS_CSG, PER_LANE>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
     }
 #if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
     {
@@ -1494,7 +1501,8 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
-        intensities<HAS_CSG, PER_LANE>(S, A, on, rec_idx, over, rng, flops, err, n_shadow);
+        const V3 normal = mk(A.R.nx[rec_idx], A.R.ny[rec_idx], A.R.nz[rec_idx]);
+        intensities<HAS_CSG, PER_LANE>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
@@ -2023,6 +2031,7 @@ struct rt_scene {
     size_t stage_pixels = 0;
     size_t chunk_pixels = (size_t)16 << 20;
     size_t recs_per_pixel = 24;
+    uint32_t min_chunks = 4;
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
 };
@@ -2526,6 +2535,10 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
             if (value > 2) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave) or 2 (lane)");
             s->traversal = (int)value;
             return RT_OK;
+        case RT_OPT_MIN_CHUNKS:
+            if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "min_chunks must be in 1..64");
+            s->min_chunks = (uint32_t)value;
+            return RT_OK;
         case RT_OPT_GRID_BLOCKS:
             if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 1..65536");
             s->grid_blocks = (uint32_t)value;
@@ -2579,10 +2592,10 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     // waits; chunks whose rays did not fit their record arrays are split and go round again.
     uint32_t chunk_rows = (uint32_t)std::max<size_t>(8, (s->chunk_pixels / W) & ~(size_t)7);
     if ((size_t)rows * W >= ((size_t)1 << 20)) {
-        // at least four chunks for a frame of a megapixel or more, so that both streams stay busy
+        // at least min_chunks chunks for a frame of a megapixel or more, so that all streams stay busy
         // (a rank of a multi-GPU job only renders its share of the rows)
-        uint32_t quarter = ((rows + 3) / 4 + 7) & ~7u;
-        chunk_rows = std::max(8u, std::min(chunk_rows, quarter));
+        uint32_t share = ((rows + s->min_chunks - 1) / s->min_chunks + 7) & ~7u;
+        chunk_rows = std::max(8u, std::min(chunk_rows, share));
     }
     struct Job { uint32_t r0, nr; };
     std::vector<Job> pending;
