@@ -59,6 +59,7 @@ constexpr int CSG_DEPTH = 6;       // nested csg levels
 constexpr int CONT_CAP = 32;       // intersections at or before a refractive hit
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
+constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one step are sorted into (power of two, <= 64)
 #ifndef FEW_RAYS_MAX
 #define FEW_RAYS_MAX 16384
 #endif
@@ -1274,8 +1275,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     if (blockIdx.x == 0 && threadIdx.x == 0) A.levels[A.level + 1].base = next_rec_base;
     __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
-    __shared__ uint32_t s_count[2][TRACE_BLOCK / 64];
+    __shared__ uint32_t s_hist[2][SPAWN_BINS], s_off[2][SPAWN_BINS];
     __shared__ uint32_t s_base[2];
+    if (threadIdx.x < SPAWN_BINS) s_hist[0][threadIdx.x] = 0u;
+    __syncthreads();
     double big_t[CONT_CAP];
     uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
     RecordBuf buf;
@@ -1390,42 +1393,46 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
         flops += F_SCHLICK;
     }
 
-    // append children to the next level: one atomic per block (the counter is a single word,
-    // so per-wave atomics would serialise)
-    unsigned long long b_refl = __ballot(spawn_refl), b_refr = __ballot(spawn_refr);
-    uint32_t n_refl = __popcll(b_refl), n_refr = __popcll(b_refr);
-    uint32_t child_refl = NONE, child_refr = NONE;
-    if (lane == 0) s_count[parity][wave_in_block] = n_refl + n_refr;
+    // Append the children to the next level: one atomic per block and step (the counter is a single
+    // word, so per-wave atomics would serialise).  Inside the block's range the children are grouped
+    // by (object they start on, reflected / refracted): the next level's waves then hold rays that
+    // meet the same objects, and a test culled for one lane is more often culled for all 64.  Which
+    // record a ray gets does not matter to anything else.
+    const uint32_t bin_base = (hit_pos >> 1) * 2u;
+    uint32_t child_refl = NONE, child_refr = NONE, rank_refl = 0, rank_refr = 0;
+    if (threadIdx.x < SPAWN_BINS) s_hist[parity ^ 1u][threadIdx.x] = 0u;  // for the next step (see the barriers)
+    if (spawn_refl) rank_refl = atomicAdd(&s_hist[parity][bin_base & (SPAWN_BINS - 1u)], 1u);
+    if (spawn_refr) rank_refr = atomicAdd(&s_hist[parity][(bin_base + 1u) & (SPAWN_BINS - 1u)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t total = 0;
-        for (uint32_t k = 0; k < TRACE_BLOCK / 64; k++) total += s_count[parity][k];
-        s_base[parity] = total ? atomicAdd(&A.levels[A.level + 1].n, total) : 0u;
+    if (threadIdx.x < 64) {  // exclusive scan of the bins by the first wave
+        uint32_t c = threadIdx.x < SPAWN_BINS ? s_hist[parity][threadIdx.x] : 0u, incl = c;
+#pragma unroll
+        for (int off = 1; off < (int)SPAWN_BINS; off <<= 1) {
+            uint32_t o = (uint32_t)__shfl_up((int)incl, off, WAVE);
+            if ((int)lane >= off) incl += o;
+        }
+        if (threadIdx.x < SPAWN_BINS) s_off[parity][threadIdx.x] = incl - c;
+        if (threadIdx.x == SPAWN_BINS - 1u) s_base[parity] = incl ? atomicAdd(&A.levels[A.level + 1].n, incl) : 0u;
     }
     __syncthreads();
     PHASE(6);
-    if (n_refl + n_refr > 0) {
-        uint32_t base = s_base[parity];
-        for (uint32_t k = 0; k < wave_in_block; k++) base += s_count[parity][k];
-        unsigned long long below = (1ull << lane) - 1ull;
-        if (spawn_refl) {
-            uint32_t c = next_rec_base + base + __popcll(b_refl & below);
-            if (c < A.rec_cap) {
-                V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
-                A.R.ox[c] = over.x; A.R.oy[c] = over.y; A.R.oz[c] = over.z;
-                A.R.dx[c] = d_.x; A.R.dy[c] = d_.y; A.R.dz[c] = d_.z;
-                child_refl = c;
-            } else err |= 1u;
-        }
-        if (spawn_refr) {
-            uint32_t c = next_rec_base + base + n_refl + __popcll(b_refr & below);
-            if (c < A.rec_cap) {
-                V3 o_ = under_point_of(point, normal);
-                A.R.ox[c] = o_.x; A.R.oy[c] = o_.y; A.R.oz[c] = o_.z;
-                A.R.dx[c] = refr_dir.x; A.R.dy[c] = refr_dir.y; A.R.dz[c] = refr_dir.z;
-                child_refr = c;
-            } else err |= 1u;
-        }
+    if (spawn_refl) {
+        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][bin_base & (SPAWN_BINS - 1u)] + rank_refl;
+        if (c < A.rec_cap) {
+            V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
+            A.R.ox[c] = over.x; A.R.oy[c] = over.y; A.R.oz[c] = over.z;
+            A.R.dx[c] = d_.x; A.R.dy[c] = d_.y; A.R.dz[c] = d_.z;
+            child_refl = c;
+        } else err |= 1u;
+    }
+    if (spawn_refr) {
+        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][(bin_base + 1u) & (SPAWN_BINS - 1u)] + rank_refr;
+        if (c < A.rec_cap) {
+            V3 o_ = under_point_of(point, normal);
+            A.R.ox[c] = o_.x; A.R.oy[c] = o_.y; A.R.oz[c] = o_.z;
+            A.R.dx[c] = refr_dir.x; A.R.dy[c] = refr_dir.y; A.R.dz[c] = refr_dir.z;
+            child_refr = c;
+        } else err |= 1u;
     }
     if (on) {
         A.R.hit_pos[rec_idx] = hit ? hit_pos : NONE;
@@ -1439,7 +1446,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     }
 
     PHASE(7);
-    n_spawned += n_refl + n_refr;  // wave-uniform
+    n_spawned += (spawn_refl ? 1u : 0u) + (spawn_refr ? 1u : 0u);
     if (hit) n_shade++;
     // the shadow rays of this hit, unless the lights need the chunk's rng order first (k_shadow):
     // their arithmetic fills the issue slots this kernel leaves idle while it waits for memory
@@ -1461,12 +1468,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     }  // steps
 
     // statistics: one atomic per wave and counter
-    uint32_t s_shade = wave_sum_u32(n_shade);
+    uint32_t s_shade = wave_sum_u32(n_shade), s_spawned = wave_sum_u32(n_spawned);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
-        if (n_spawned) atomicAdd(&st->secondary, (unsigned long long)n_spawned);
+        if (s_spawned) atomicAdd(&st->secondary, (unsigned long long)s_spawned);
         if (s_shade) atomicAdd(&st->shade, (unsigned long long)s_shade);
         atomicAdd(&st->flop_trace, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
     }
