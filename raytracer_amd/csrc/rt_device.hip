@@ -1608,9 +1608,16 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         const double* mat_rec = t_mat + (size_t)t_stream[(size_t)hit_pos * 16 + 1] * 8;
         const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
         const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
-        V3 object_point = mul_point_v(leaf_inverse(t_stream, S.xform, hit_pos), over);
+        // a solid root pattern ignores the point (pattern/solid.rs:19): no object-space transform needed
+        const uint32_t pat_root = (uint32_t)mat_rec[7];
+        V3 pat;
+        if (pt.pat_meta[pat_root * 4] == RT_PAT_SOLID) {
+            pat = mk(pt.pat_col[pat_root * 4 + 0], pt.pat_col[pat_root * 4 + 1], pt.pat_col[pat_root * 4 + 2]);
+        } else {
+            V3 object_point = mul_point_v(leaf_inverse(t_stream, S.xform, hit_pos), over);
+            pat = pattern_eval(pt, pat_root, object_point);
+        }
         PHASE(2);
-        const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
         PHASE(3);
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
