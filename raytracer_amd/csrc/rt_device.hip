@@ -60,10 +60,9 @@ constexpr int CONT_CAP = 32;       // intersections at or before a refractive hi
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
 constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one step are sorted into (power of two, <= 64)
-#ifndef FEW_RAYS_MAX
-#define FEW_RAYS_MAX 16384
-#endif
-constexpr uint32_t FEW_RAYS = FEW_RAYS_MAX;  // a level of a lane-walked tree with at most this many rays gets a wave per ray
+// A level of a lane-walked tree with at most this many rays gets a wave per
+// ray; the larger bound holds when triangle runs are tested 64 at a time.
+constexpr uint32_t FEW_RAYS = 16384, FEW_RAYS_RUNS = 262144;
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 4     // occupancy the compiler must reach for k_trace (waves per SIMD; csg variants: 2)
 #endif
@@ -1288,7 +1287,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
     // a lane-walked tree and few rays: one wave per ray (see traverse<ONE_RAY>)
-    const bool few = PER_LANE && !PRIMARY && n_rays <= FEW_RAYS;
+    const bool few = PER_LANE && !PRIMARY && n_rays <= (record ? FEW_RAYS : FEW_RAYS_RUNS);
     const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
                              : few   ? (n_rays + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
                                      : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
