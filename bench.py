@@ -33,6 +33,7 @@ WORKLOADS = {
     "chapter6-1000x1000": ("scenes/chapter6.yaml", 2.0, 5),
     "spheres-3000x2400-depth20": (None, 3.0, 20),
     "chapter15-dragon-1000x1000": ("scenes/chapter15-dragon.yaml", 1.0, 5),
+    "bounding-box-1000x400": ("scenes/bounding-box.yaml", 1.0, 5),
     "chapter16-1000x1000": ("scenes/chapter16.yaml", 1.0, 5),
     "area-light-800x320": ("scenes/area-light.yaml", 1.0, 5),
 }
@@ -151,7 +152,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "the reference's own scene file (scenes/chapter11.yaml, --seed 0); no synthetic substitute is needed"
+            "data": "the reference's own scene file (%s, --seed %d); no synthetic substitute is needed" % (scene_file, args.seed)
             if scene_file else "generated sphere scene (--sphere-scene --seed %d)" % args.seed,
             "config": {
                 "workload": args.workload, "width": W, "height": H, "depth": depth, "seed": args.seed,

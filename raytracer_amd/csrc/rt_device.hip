@@ -138,7 +138,7 @@ constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
     uint32_t n_materials, n_patterns;
-    uint32_t flags;             // bit0: some material has a nonzero transparency
+    uint32_t flags;             // bit0: some material has a nonzero transparency; bit1: shadow rays may stop at their first hit
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
     const double* tri_normals;  // n_tris*9
@@ -384,6 +384,12 @@ DEV Walk walk_init() {
     w.t = 0.0; w.pos = NONE; w.w0 = 0; w.mat = 0; w.cls = 0; w.arrival = 0; w.nan_seen = false; w.n = 0; w.overflow = false;
     return w;
 }
+constexpr uint32_t LIMIT = 0xFFFFFFFEu;  // Walk::pos of a walk that only has a distance bound so far
+DEV Walk walk_init_below(double bound) {
+    Walk w = walk_init();
+    w.t = bound; w.pos = LIMIT;
+    return w;
+}
 
 // Where a walk keeps the (t, unit position, class) of its candidates: entry k of this lane is at
 // index k*stride.
@@ -399,12 +405,20 @@ struct ContBuf {
 struct RecordBuf {
     ContBuf fast, big;
     static constexpr bool enabled = true;
+    static constexpr bool any_hit = false;
     DEV int cap() const { return big.cap; }
     DEV void put(int k, double tt, uint32_t p, uint32_t c) const {
         if (k < fast.cap) fast.put(k, tt, p, c); else big.put(k, tt, p, c);
     }
 };
-struct NoRecord {  // shadow rays only need the closest hit
+// Shadow rays only need the closest hit below the light's distance: their walk starts with that
+// distance as the bound to beat (position LIMIT = nothing found yet), so everything beyond the
+// light is culled like anything beyond a hit.  World::is_shadowed (world.rs:117-123) asks whether
+// the closest hit casts a shadow and lies before the light; a closest hit at or beyond the light
+// answers no, as does finding nothing.  When every leaf of the scene casts a shadow the first hit
+// found before the light already settles it: with `any_hit` the lane stops walking there.
+struct NoRecord {
+    bool any_hit;
     static constexpr bool enabled = false;
     DEV int cap() const { return 0; }
     DEV void put(int, double, uint32_t, uint32_t) const {}
@@ -503,6 +517,9 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     for (;;) {
         if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
         if (i >= n) break;
+        if constexpr (!Buf::enabled) {
+            if (cb.any_hit && w.pos < LIMIT) skip_until = NONE;
+        }
         bool act = skip_until <= i;
         if (__ballot(act) == 0ull) {
             i = wave_min_u32(skip_until);
@@ -679,6 +696,9 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
     uint32_t i = lane_on ? 0u : n;
     for (;;) {
         if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
+        if constexpr (!Buf::enabled) {
+            if (cb.any_hit && w.pos < LIMIT) i = n;
+        }
         const bool act = i < n;
         if (__ballot(act) == 0ull) break;
         const uint32_t* rec = S.stream + (size_t)(act ? i : 0u) * 16;
@@ -1244,13 +1264,13 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             // whatever is_shadowed answers is multiplied by zero.  The ray still counts as cast.
             const bool moot = !is_area && dot(sr.d, normal) < 0.0;
             const bool cast = on && !moot;
-            Walk w = walk_init();
+            Walk w = walk_init_below(distance);
             if (__ballot(cast) != 0ull) {
-                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, cast, false, w, NoRecord{}, flops, true, err);
+                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, cast, false, w, NoRecord{(S.flags & 2u) != 0}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
             }
             bool shadowed = moot;  // reported as intensity 0: k_shade then skips the light's loop as well
-            if (cast && w.pos != NONE) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
+            if (cast && w.pos < LIMIT) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
             if (!shadowed) unshadowed += 1.0;
             if (on) { flops += F_SHADOW; n_shadow++; }
         }
@@ -2504,6 +2524,14 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->dev.flags = 0;
     for (uint32_t i = 0; i < d->n_materials; i++)
         if (d->material[(size_t)i * 7 + 5] != 0.0) s->dev.flags |= 1u;
+    {
+        bool all_cast = true;
+        for (uint32_t i = 0; i < d->n_leaves; i++) all_cast = all_cast && d->leaf_casts_shadow[i] != 0;
+        // Stopping at the first hit pays in the long walks through a mesh; in a scene of a few objects
+        // the wave finishes together anyway, and there the work counters keep describing the
+        // reference's full walk.
+        if (all_cast && units > PER_LANE_MIN_UNITS) s->dev.flags |= 2u;
+    }
     UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(cull, cull); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
     UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);
     UP(light_meta, light_meta);
