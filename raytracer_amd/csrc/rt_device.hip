@@ -135,6 +135,7 @@ struct Ray { V3 o, d; };
 //       its inverse lives in `xform` (meshes share one matrix, so a wave transforms its rays once
 //       per matrix, not once per triangle) and its vertex normals in `tri_normals`.
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
+constexpr uint32_t MESH_BIT = 1u << 12;  // group header w0: the subtree is a mesh with a hierarchy of its own (w2 root, w3 matrix)
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
     uint32_t n_materials, n_patterns;
@@ -151,6 +152,9 @@ struct DevScene {
     const double* pat_col;      // n_patterns*4
     const double* light;        // n_lights*12
     const uint32_t* light_meta; // n_lights*4: kind, usteps, vsteps, 0
+    const double* bvh;          // 16 f64 per inner node of the mesh hierarchies (see mesh_walk)
+    const uint32_t* bvh_tris;   // unit positions of the triangles of the hierarchies' leaves
+    const uint32_t* parent;     // n_units: unit position of the enclosing group / csg, NONE at the top
 };
 
 // Algorithmic FLOP constants (f64 add/sub/mul/div/sqrt/compare in the
@@ -664,6 +668,123 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     }
 }
 
+// ---------------------------------------------------------------- meshes
+// A group whose subtree holds nothing but triangles under one matrix (an OBJ mesh, divided or not)
+// carries a second, device-only hierarchy over the same triangles: a binary tree built with the
+// surface-area heuristic in the mesh's object space, four triangles or fewer per leaf, walked
+// nearest child first with a small stack.  The reference's own tree is whatever Group::divide
+// (object/group/mod.rs:50-139) made of the file's order - children that straddle a split stay in
+// the parent, the walk order is fixed - so a ray through it tests many times more boxes and
+// triangles than it has to.
+//
+// What the reference's list would hold is reproduced exactly:
+//  * the triangle test is the reference's, on the same object-space ray;
+//  * an intersection only counts if the ray also passes, by the reference's own predicate, the
+//    stored box of every group between the triangle and the mesh's root (a ray can graze a triangle
+//    on the rim of a box that rounding makes it miss); the root's box was tested on the way in;
+//  * intersections arrive in another order than the reference's, so ties in t go to the lower
+//    stream position, which is the earlier arrival of the reference's walk.
+// The hierarchy's boxes are padded and tested with slack: they only have to be conservative.
+// Walks that record what sorts before the hit keep to the reference's tree.
+constexpr int BVH_STACK = 64;
+constexpr uint32_t BVH_LEAF = 0x80000000u;  // reference to a leaf: BVH_LEAF | (count - 1) << 27 | first entry of bvh_tris
+
+// Does the ray pass the stored boxes of the groups strictly between unit position `pos` and `root`?
+DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32_t pos, uint32_t root) {
+    const V3 P = ray.o + ray.d * t;
+    uint32_t g = S.parent[pos];
+    for (int k = 0; k < BVH_STACK && g != root && g != NONE; k++) {
+        const double* b = (const double*)(S.stream + (size_t)g * 16);
+        const double x0 = b[2], y0 = b[3], z0 = b[4], x1 = b[5], y1 = b[6], z1 = b[7];
+        // a hit point well inside the box (margin far above the rounding of either computation)
+        // settles it; otherwise the reference's test decides
+        const double mx = 1e-9 * (fabs(x0) + fabs(x1) + fabs(ray.o.x) + fabs(P.x));
+        const double my = 1e-9 * (fabs(y0) + fabs(y1) + fabs(ray.o.y) + fabs(P.y));
+        const double mz = 1e-9 * (fabs(z0) + fabs(z1) + fabs(ray.o.z) + fabs(P.z));
+        const bool inside = t > 0.0 && P.x > x0 + mx && P.x < x1 - mx && P.y > y0 + my && P.y < y1 - my && P.z > z0 + mz &&
+                            P.z < z1 - mz;
+        if (!inside) {
+            double ta, tb;
+            if (!box_intersect(ray, x0, y0, z0, x1, y1, z1, ta, tb)) return false;
+        }
+        g = S.parent[g];
+    }
+    return true;
+}
+
+// Closest intersection of one lane's ray with a mesh (no recording).  `ray` is the world-space ray.
+DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, Walk& w, bool any_hit,
+                   uint32_t& flops, bool count) {
+    const double* m = S.xform + (size_t)xf * 12;
+    Ray r;
+    r.o = mul_point_v(m, ray.o);
+    r.d = mul_vector_v(m, ray.d);
+    const V3 inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    uint32_t stack[BVH_STACK];
+    double stack_t[BVH_STACK];
+    int sp = 0;
+    uint32_t cur = root_ref;
+    const double huge = __builtin_huge_val();
+    for (;;) {
+        const double hi = w.pos == NONE ? huge : w.t * (1.0 + CULL_REL) + CULL_ABS;
+        if (cur == NONE) {
+            while (sp > 0) {
+                sp--;
+                if (!(stack_t[sp] > hi)) { cur = stack[sp]; break; }
+            }
+            if (cur == NONE) break;
+        }
+        if (cur & BVH_LEAF) {
+            const uint32_t at = cur & 0x07FFFFFFu, left = (cur >> 27) & 15u;
+            cur = left ? (BVH_LEAF | ((left - 1u) << 27) | (at + 1u)) : NONE;
+            const uint32_t pos = S.bvh_tris[at];
+            const uint32_t* lr = S.stream + (size_t)pos * 16;
+            const double* ld = (const double*)lr;
+            double t, u, v;
+            const bool got = triangle_hit(r, mk(ld[4], ld[5], ld[6]), mk(ld[7], ld[8], ld[9]), mk(ld[10], ld[11], ld[12]), t, u, v);
+            if (count) flops += F_XFORM + F_TRI;
+            if (got) {
+                if (t != t) w.nan_seen = true;
+                w.arrival++;
+                const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
+                if (t > 0.0 && below && mesh_ancestors_pass(S, ray, t, pos, root_pos)) {
+                    w.t = t; w.pos = pos; w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
+                    if (any_hit) break;
+                }
+            }
+        } else {
+            const double* nd = S.bvh + (size_t)cur * 16;
+            double b[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) b[k] = nd[k];
+            const uint32_t c0 = (uint32_t)__double2loint(nd[12]), c1 = (uint32_t)__double2hiint(nd[12]);
+            if (count) flops += 2 * F_BOX;
+            double near_[2];
+            bool hit_[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const double ax = (b[c * 6 + 0] - r.o.x) * inv.x, bx = (b[c * 6 + 3] - r.o.x) * inv.x;
+                const double ay = (b[c * 6 + 1] - r.o.y) * inv.y, by = (b[c * 6 + 4] - r.o.y) * inv.y;
+                const double az = (b[c * 6 + 2] - r.o.z) * inv.z, bz = (b[c * 6 + 5] - r.o.z) * inv.z;
+                // fmin / fmax drop a NaN operand (0 * inf: the origin on the face of a slab the ray runs along)
+                const double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+                const double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+                const double slack = 1e-12 * (fmin(fabs(tn), 1e300) + fmin(fabs(tf), 1e300)) + 1e-300;
+                near_[c] = tn;
+                hit_[c] = tn <= tf + slack && tn <= hi && tf + slack >= 0.0;
+            }
+            if (hit_[0] && hit_[1]) {
+                const bool swap = near_[1] < near_[0];
+                const uint32_t first = swap ? c1 : c0, second = swap ? c0 : c1;
+                if (sp < BVH_STACK) { stack[sp] = second; stack_t[sp] = swap ? near_[0] : near_[1]; sp++; }
+                cur = first;
+            } else {
+                cur = hit_[0] ? c0 : (hit_[1] ? c1 : NONE);
+            }
+        }
+    }
+}
+
 // The same walk with one position per lane, for trees too large for the wave to walk together
 // (meshes): each lane follows its own path through the skip links, loading nodes with vector
 // loads, so a lane only pays for the boxes and leaves its own ray reaches.  Lanes at different
@@ -718,6 +839,16 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             if (count) flops += F_BOX;
             if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             uint32_t next = hit ? i + 1 : w1;
+            if constexpr (CULL) {
+                bool in_csg = false;
+                if constexpr (HAS_CSG) in_csg = cs_top > 0;
+                if (hit && (w0 & MESH_BIT) && !(Buf::enabled && record) && !in_csg) {
+                    bool any_hit = false;
+                    if constexpr (!Buf::enabled) any_hit = cb.any_hit;
+                    mesh_walk(S, ray, i, w2, w3, w, any_hit, flops, count);
+                    next = w1;
+                }
+            }
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && hit) {
                     if (cs_top < CSG_DEPTH) {
@@ -2001,6 +2132,107 @@ bool bounding_sphere(uint32_t shape, const double* inv, double mn, double mx, do
     return true;
 }
 
+// ---- the meshes' own hierarchies (see mesh_walk)
+struct MeshTri { double lo[3], hi[3], c[3]; uint32_t pos; };
+struct MeshBuild { std::vector<double> nodes; std::vector<uint32_t> tris; };
+constexpr uint32_t MESH_MIN_TRIS = 4, MESH_LEAF_TRIS = 4;
+
+void mesh_bounds(const MeshTri* t, size_t n, double* lo, double* hi) {
+    for (int a = 0; a < 3; a++) { lo[a] = HUGE_VAL; hi[a] = -HUGE_VAL; }
+    for (size_t k = 0; k < n; k++)
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], t[k].lo[a]); hi[a] = std::max(hi[a], t[k].hi[a]); }
+}
+double half_area(const double* lo, const double* hi) {
+    double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+// Builds the subtree over t[b, e) and returns its reference.  Splits by the surface-area heuristic
+// over 16 centroid bins per axis; below `depth` 32 a split that fails to separate anything, and
+// every split beyond, halves the range at the median, which bounds the depth by 32 + log2(n).
+uint32_t mesh_build(std::vector<MeshTri>& t, size_t b, size_t e, int depth, MeshBuild& out) {
+    const size_t n = e - b;
+    if (n <= MESH_LEAF_TRIS) {
+        uint32_t at = (uint32_t)out.tris.size();
+        std::sort(t.begin() + b, t.begin() + e, [](const MeshTri& x, const MeshTri& y) { return x.pos < y.pos; });
+        for (size_t k = b; k < e; k++) out.tris.push_back(t[k].pos);
+        return BVH_LEAF | ((uint32_t)(n - 1) << 27) | at;
+    }
+    double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+    for (size_t k = b; k < e; k++)
+        for (int a = 0; a < 3; a++) { clo[a] = std::min(clo[a], t[k].c[a]); chi[a] = std::max(chi[a], t[k].c[a]); }
+    size_t mid = b;
+    bool split = false;
+    if (depth < 32) {
+        constexpr int BINS = 16;
+        double best = HUGE_VAL, best_edge = 0.0;
+        int best_axis = -1;
+        for (int a = 0; a < 3; a++) {
+            const double ext = chi[a] - clo[a];
+            if (!(ext > 0.0)) continue;
+            size_t cnt[BINS] = {0};
+            double blo[BINS][3], bhi[BINS][3];
+            for (int i = 0; i < BINS; i++) for (int q = 0; q < 3; q++) { blo[i][q] = HUGE_VAL; bhi[i][q] = -HUGE_VAL; }
+            for (size_t k = b; k < e; k++) {
+                int bin = std::min(BINS - 1, std::max(0, (int)((t[k].c[a] - clo[a]) / ext * BINS)));
+                cnt[bin]++;
+                for (int q = 0; q < 3; q++) { blo[bin][q] = std::min(blo[bin][q], t[k].lo[q]); bhi[bin][q] = std::max(bhi[bin][q], t[k].hi[q]); }
+            }
+            double rarea[BINS];
+            size_t rcnt[BINS];
+            double lo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, hi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
+            size_t c = 0;
+            for (int i = BINS - 1; i > 0; i--) {
+                for (int q = 0; q < 3; q++) { lo[q] = std::min(lo[q], blo[i][q]); hi[q] = std::max(hi[q], bhi[i][q]); }
+                c += cnt[i];
+                rarea[i] = c ? half_area(lo, hi) : 0.0;
+                rcnt[i] = c;
+            }
+            for (int q = 0; q < 3; q++) { lo[q] = HUGE_VAL; hi[q] = -HUGE_VAL; }
+            c = 0;
+            for (int i = 0; i + 1 < BINS; i++) {
+                for (int q = 0; q < 3; q++) { lo[q] = std::min(lo[q], blo[i][q]); hi[q] = std::max(hi[q], bhi[i][q]); }
+                c += cnt[i];
+                if (c == 0 || rcnt[i + 1] == 0) continue;
+                double cost = half_area(lo, hi) * (double)c + rarea[i + 1] * (double)rcnt[i + 1];
+                if (cost < best) { best = cost; best_axis = a; best_edge = clo[a] + ext * (double)(i + 1) / BINS; }
+            }
+        }
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const double ext = chi[a] - clo[a];
+            auto it = std::partition(t.begin() + b, t.begin() + e, [&](const MeshTri& x) {
+                int bin = std::min(15, std::max(0, (int)((x.c[a] - clo[a]) / ext * 16)));
+                return clo[a] + ext * (double)(bin + 1) / 16 <= best_edge;
+            });
+            mid = (size_t)(it - t.begin());
+            split = mid > b && mid < e;
+        }
+    }
+    if (!split) {
+        int a = 0;
+        for (int q = 1; q < 3; q++) if (chi[q] - clo[q] > chi[a] - clo[a]) a = q;
+        mid = b + n / 2;
+        std::nth_element(t.begin() + b, t.begin() + mid, t.begin() + e,
+                         [a](const MeshTri& x, const MeshTri& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.pos < y.pos); });
+    }
+    const size_t node = out.nodes.size() / 16;
+    out.nodes.resize(out.nodes.size() + 16, 0.0);
+    const uint32_t c0 = mesh_build(t, b, mid, depth + 1, out), c1 = mesh_build(t, mid, e, depth + 1, out);
+    double* nd = &out.nodes[node * 16];
+    for (int c = 0; c < 2; c++) {
+        double lo[3], hi[3];
+        mesh_bounds(&t[c ? mid : b], c ? e - mid : mid - b, lo, hi);
+        for (int q = 0; q < 3; q++) {
+            const double pad = 1e-9 * std::max(std::max(std::fabs(lo[q]), std::fabs(hi[q])), hi[q] - lo[q]) + 1e-30;
+            nd[c * 6 + q] = lo[q] - pad;
+            nd[c * 6 + 3 + q] = hi[q] + pad;
+        }
+    }
+    uint32_t refs[2] = {c0, c1};
+    std::memcpy(&nd[12], refs, 8);
+    return (uint32_t)node;
+}
+
 template <class T>
 int upload(const std::vector<T>& host, T** dev) {
     size_t bytes = (host.size() ? host.size() : 1) * sizeof(T);
@@ -2476,6 +2708,70 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         }
     }
 
+    // enclosing node of every unit, and the meshes: the topmost groups outside any csg whose
+    // leaves are all triangles under one matrix
+    std::vector<uint32_t> parent_unit((size_t)units + 4, NONE);
+    MeshBuild meshes;
+    {
+        std::vector<uint32_t> parent_node(d->n_nodes, NONE), open;
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            while (!open.empty() && d->node_skip[open.back()] <= i) open.pop_back();
+            parent_node[i] = open.empty() ? NONE : open.back();
+            if (d->node_kind[i] != RT_NODE_LEAF) open.push_back(i);
+        }
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            uint32_t pu = parent_node[i] == NONE ? NONE : unit_of[parent_node[i]];
+            parent_unit[unit_of[i]] = pu;
+            if (d->node_kind[i] == RT_NODE_LEAF) parent_unit[unit_of[i] + 1] = pu;
+        }
+        constexpr uint32_t MIXED = 0xFFFFFFFEu;           // more than one matrix, or something that is no triangle
+        std::vector<uint32_t> matrix(d->n_nodes, NONE);   // NONE: nothing below yet
+        std::vector<uint32_t> n_below(d->n_nodes, 0), levels(d->n_nodes, 0);
+        for (uint32_t i = d->n_nodes; i-- > 0;) {         // children come after their parent: fold them in backwards
+            if (d->node_kind[i] == RT_NODE_LEAF) {
+                bool tri = d->leaf_shape[d->node_arg[i]] == RT_TRIANGLE;
+                matrix[i] = tri ? stream[(size_t)unit_of[i] * 16 + 4] : MIXED;
+                n_below[i] = tri ? 1 : 0;
+            } else if (d->node_kind[i] == RT_NODE_CSG) {
+                matrix[i] = MIXED;
+            }
+            uint32_t par = parent_node[i];
+            if (par != NONE) {
+                if (matrix[i] != NONE) matrix[par] = (matrix[par] == NONE || matrix[par] == matrix[i]) ? matrix[i] : MIXED;
+                n_below[par] += n_below[i];
+                levels[par] = std::max(levels[par], levels[i] + 1);
+            }
+        }
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            if (d->node_kind[i] != RT_NODE_GROUP || matrix[i] == NONE || matrix[i] == MIXED) continue;
+            if (parent_node[i] != NONE && matrix[parent_node[i]] != MIXED) continue;   // part of a larger mesh
+            if (n_below[i] < MESH_MIN_TRIS || n_below[i] >= (1u << 27) || levels[i] >= (uint32_t)BVH_STACK - 2) continue;
+            if (inside_csg(i)) continue;
+            std::vector<MeshTri> tris;
+            tris.reserve(n_below[i]);
+            bool finite = true;
+            for (uint32_t j = i + 1; j < d->node_skip[i]; j++) {
+                if (d->node_kind[j] != RT_NODE_LEAF) continue;
+                const double* v = (const double*)&stream[(size_t)unit_of[j] * 16] + 4;  // p1, e1, e2
+                MeshTri mt;
+                mt.pos = unit_of[j];
+                for (int a = 0; a < 3; a++) {
+                    const double p0 = v[a], p1 = v[a] + v[3 + a], p2 = v[a] + v[6 + a];
+                    mt.lo[a] = std::min(p0, std::min(p1, p2));
+                    mt.hi[a] = std::max(p0, std::max(p1, p2));
+                    mt.c[a] = 0.5 * (mt.lo[a] + mt.hi[a]);
+                    finite = finite && std::isfinite(mt.lo[a]) && std::isfinite(mt.hi[a]);
+                }
+                tris.push_back(mt);
+            }
+            if (!finite) continue;
+            uint32_t* rec = &stream[(size_t)unit_of[i] * 16];
+            rec[2] = mesh_build(tris, 0, tris.size(), 0, meshes);
+            rec[3] = matrix[i];
+            rec[0] |= MESH_BIT;
+        }
+    }
+
     auto* s = new rt_scene();
     (void)hipGetDevice(&s->device);
     s->has_csg = has_csg;
@@ -2535,6 +2831,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(cull, cull); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
     UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);
     UP(light_meta, light_meta);
+    UP(meshes.nodes, bvh); UP(meshes.tris, bvh_tris); UP(parent_unit, parent);
 #undef UP
     *out = s;
     return RT_OK;

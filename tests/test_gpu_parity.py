@@ -97,7 +97,9 @@ def test_render_is_deterministic_and_depth_zero_has_no_secondary_rays():
     ("scenes/chapter15.yaml", 0.2, 5), ("scenes/bounding-box.yaml", 0.15, 5), ("scenes/area-light.yaml", 0.25, 5)])
 def test_both_tree_walks_give_the_same_image(scene, scale, depth):
     """The wave-uniform walk and the lane-by-lane walk (meshes) are two schedules of the same
-    arithmetic: bit-identical f64 frames and ray counts, whichever the tree size would select."""
+    arithmetic: bit-identical f64 frames and ray counts, whichever the tree size would select.
+    The lane-by-lane walk goes through a mesh by its own hierarchy and so counts fewer tests:
+    the work counters only have to agree for scenes without a mesh."""
     frames = []
     for mode in (1, 2):
         g, _ = pair(scene, scale)
@@ -108,8 +110,11 @@ def test_both_tree_walks_give_the_same_image(scene, scale, depth):
     (a, sa), (b, sb) = frames
     assert np.array_equal(a.pixels.view(np.uint64), b.pixels.view(np.uint64))
     assert np.array_equal(a.rgb8, b.rgb8)
-    for key in ("secondary_rays", "shadow_rays", "shade_hits", "flop_trace", "flop_shadow"):
+    has_mesh = scene in ("scenes/chapter15.yaml", "scenes/bounding-box.yaml")
+    for key in ("secondary_rays", "shadow_rays", "shade_hits") + (() if has_mesh else ("flop_trace", "flop_shadow")):
         assert sa[key] == sb[key], key
+    if has_mesh:
+        assert sb["flop_trace"] < sa["flop_trace"] and sb["flop_shadow"] < sa["flop_shadow"]
 
 
 @pytest.mark.parametrize("scene,depth", [("scenes/chapter11.yaml", 30), ("scenes/area-light.yaml", 5)])
