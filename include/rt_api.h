@@ -67,7 +67,13 @@ typedef struct rt_scene_desc {
     const uint32_t *node_arg;  /* leaf: leaf index; csg: csg index; group: unused   */
     const double *node_bbox;   /* n_nodes*6: min xyz, max xyz of the STORED box of a
                                   group / csg (src/object/group/mod.rs:20,
-                                  src/object/csg/mod.rs:18); ignored for leaves     */
+                                  src/object/csg/mod.rs:18); ignored for leaves.  A
+                                  csg's box may be stale (csg/mod.rs:117-121) and only
+                                  ever decides what the reference lets it decide; a
+                                  group's box must hold everything below it, as
+                                  Group::bounding_box sees to (group/mod.rs:109-139):
+                                  the walk skips a group it enters beyond the closest
+                                  hit so far                                        */
 
     uint32_t n_leaves;
     const uint32_t *leaf_shape;    /* RT_SPHERE ...                                 */
@@ -216,7 +222,10 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 4096)
  *   RT_OPT_TRAVERSAL       0: chosen by tree size (default); 1: the 64 lanes of a
  *                          wave walk the tree together; 2: every lane walks on
- *                          its own (large trees, meshes)
+ *                          its own (large trees; meshes by a hierarchy of their
+ *                          own); 3: the reference's walk, test for test, with none
+ *                          of the device-only shortcuts (slow; what the other
+ *                          three are checked against)
  *   RT_OPT_MIN_CHUNKS      a frame of a megapixel or more is cut into at least this
  *                          many chunks (default 4)
  */

@@ -60,9 +60,6 @@ constexpr int CONT_CAP = 32;       // intersections at or before a refractive hi
 constexpr int PAT_DEPTH = 6;       // nested pattern levels
 constexpr int WAVE = 64;
 constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one step are sorted into (power of two, <= 64)
-// A level of a lane-walked tree with at most this many rays gets a wave per
-// ray; the larger bound holds when triangle runs are tested 64 at a time.
-constexpr uint32_t FEW_RAYS = 16384, FEW_RAYS_RUNS = 262144;
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 4     // occupancy the compiler must reach for k_trace (waves per SIMD; csg variants: 2)
 #endif
@@ -171,15 +168,6 @@ DEV uint32_t wave_min_u32(uint32_t v) {
         v = o < v ? o : v;
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-DEV double wave_min_f64(double v) {  // no NaNs expected
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int lo = __shfl_xor(__double2loint(v), off, WAVE), hi = __shfl_xor(__double2hiint(v), off, WAVE);
-        double o = __hiloint2double(hi, lo);
-        v = o < v ? o : v;
-    }
-    return v;
 }
 DEV uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -414,6 +402,9 @@ struct RecordBuf {
     DEV void put(int k, double tt, uint32_t p, uint32_t c) const {
         if (k < fast.cap) fast.put(k, tt, p, c); else big.put(k, tt, p, c);
     }
+    DEV double t_at(int k) const { return k < fast.cap ? fast.t[k * fast.stride] : big.t[k * big.stride]; }
+    DEV uint32_t pos_at(int k) const { return k < fast.cap ? fast.pos[k * fast.stride] : big.pos[k * big.stride]; }
+    DEV uint32_t cls_at(int k) const { return k < fast.cap ? fast.cls[k * fast.stride] : big.cls[k * big.stride]; }
 };
 // Shadow rays only need the closest hit below the light's distance: their walk starts with that
 // distance as the bound to beat (position LIMIT = nothing found yet), so everything beyond the
@@ -426,6 +417,9 @@ struct NoRecord {
     static constexpr bool enabled = false;
     DEV int cap() const { return 0; }
     DEV void put(int, double, uint32_t, uint32_t) const {}
+    DEV double t_at(int) const { return 0.0; }
+    DEV uint32_t pos_at(int) const { return 0u; }
+    DEV uint32_t cls_at(int) const { return 0u; }
 };
 
 // Close every csg of this lane whose subtree ends at or before unit position i: stable sort of
@@ -480,11 +474,7 @@ DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uin
 // object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
 // change the closest hit or what sorts before it (w.arrival then no longer counts every
 // intersection of the reference's list; rt_probe, which reports that count, walks without it).
-// With ONE_RAY all 64 lanes carry the same ray (levels with so few rays that a wave per ray is
-// affordable): everything is redundant across the lanes except runs of sibling triangles, which
-// are tested 64 at a time, one triangle per lane - a ray's walk through a mesh is a long serial
-// chain, and the runs are most of it.
-template <bool HAS_CSG, bool CULL, class Buf, bool ONE_RAY = false>
+template <bool HAS_CSG, bool CULL, class Buf>
 DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
                   bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
@@ -552,8 +542,10 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             if (act && count) flops += F_BOX;
             uint32_t end = w1;
             // Beyond the reference's test: a box entered after the closest hit so far cannot hold a
-            // closer one (nor anything that sorts before it), so its subtree is skipped as well.
-            if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
+            // closer one (nor anything that sorts before it), so its subtree is skipped as well.  Only
+            // for groups, whose box always holds their children (object/group/mod.rs:109-115,131-139);
+            // a csg keeps the box it was built with when it is moved (object/csg/mod.rs:117-121).
+            if (CULL && kind == K_GROUP && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             if (act && !hit) skip_until = end;
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && act && hit) {
@@ -602,39 +594,6 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             if (xf != cur_xform) {  // wave-uniform: one transform per mesh matrix
                 cur_xform = xf;
                 tri_ray = to_object_u(S.xform, xf * 12, ray);
-            }
-            if constexpr (ONE_RAY) {
-                bool in_csg = false;
-                if constexpr (HAS_CSG) in_csg = cs_top > 0;
-                if (!(Buf::enabled && record) && !in_csg) {
-                    // this triangle and the siblings that follow it (q[3] low word: how many), one per
-                    // lane.  In list order the running best ends as the smallest t among those that
-                    // beat it, the earliest on ties: a minimum over the lanes, lowest lane first.
-                    const uint32_t cnt = min((uint32_t)__double2loint(q[3]) + 1u, 64u);
-                    const uint32_t ln = threadIdx.x & 63u;
-                    const bool mine = act && ln < cnt;
-                    const uint32_t* lr = S.stream + (size_t)(i + 2u * (mine ? ln : 0u)) * 16;
-                    const double* ld = (const double*)lr;
-                    double t = 0.0, u, v;
-                    const bool got = mine && triangle_hit(tri_ray, mk(ld[4], ld[5], ld[6]), mk(ld[7], ld[8], ld[9]),
-                                                          mk(ld[10], ld[11], ld[12]), t, u, v);
-                    if (mine) flops += F_XFORM + F_TRI;
-                    if (__ballot(got && t != t) != 0ull) w.nan_seen = true;
-                    w.arrival += (uint32_t)__popcll(__ballot(got));
-                    const bool better = got && t > 0.0 && (w.pos == NONE || t < w.t);
-                    const double tmin = wave_min_f64(better ? t : __builtin_huge_val());
-                    const unsigned long long winners = __ballot(better && t == tmin);
-                    if (winners != 0ull) {
-                        const int win = __ffsll((long long)winners) - 1;
-                        w.t = tmin;
-                        w.pos = i + 2u * (uint32_t)win;
-                        w.w0 = (uint32_t)__shfl((int)lr[0], win, WAVE);
-                        w.mat = (uint32_t)__shfl((int)lr[1], win, WAVE);
-                        w.cls = (uint32_t)__shfl((int)lr[3], win, WAVE);
-                    }
-                    i += 2u * cnt;
-                    continue;
-                }
             }
             V3 p1 = mk(q[4], q[5], q[6]), e1 = mk(q[7], q[8], q[9]), e2 = mk(q[10], q[11], q[12]);
             double t, u, v;
@@ -685,7 +644,9 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
 //  * intersections arrive in another order than the reference's, so ties in t go to the lower
 //    stream position, which is the earlier arrival of the reference's walk.
 // The hierarchy's boxes are padded and tested with slack: they only have to be conservative.
-// Walks that record what sorts before the hit keep to the reference's tree.
+// A walk that records what sorts before the hit (every intersection below the running best,
+// behind the origin too) puts the mesh's entries into stream order afterwards, which is the order
+// the reference's walk would have delivered them in.
 constexpr int BVH_STACK = 64;
 constexpr uint32_t BVH_LEAF = 0x80000000u;  // reference to a leaf: BVH_LEAF | (count - 1) << 27 | first entry of bvh_tris
 
@@ -712,9 +673,12 @@ DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32
     return true;
 }
 
-// Closest intersection of one lane's ray with a mesh (no recording).  `ray` is the world-space ray.
-DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, Walk& w, bool any_hit,
-                   uint32_t& flops, bool count) {
+// One lane's ray against a mesh.  `ray` is the world-space ray.
+template <class Buf>
+DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, Walk& w, bool record,
+                   Buf cb, bool any_hit, uint32_t& flops, bool count) {
+    const bool rec = Buf::enabled && record;
+    const int n_before = w.n;
     const double* m = S.xform + (size_t)xf * 12;
     Ray r;
     r.o = mul_point_v(m, ray.o);
@@ -747,9 +711,14 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
                 if (t != t) w.nan_seen = true;
                 w.arrival++;
                 const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
-                if (t > 0.0 && below && mesh_ancestors_pass(S, ray, t, pos, root_pos)) {
-                    w.t = t; w.pos = pos; w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
-                    if (any_hit) break;
+                if ((t > 0.0 || rec) && below && mesh_ancestors_pass(S, ray, t, pos, root_pos)) {
+                    if (rec) {
+                        if (w.n < cb.cap()) { cb.put(w.n, t, pos, lr[3]); w.n++; } else w.overflow = true;
+                    }
+                    if (t > 0.0) {
+                        w.t = t; w.pos = pos; w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
+                        if (any_hit) break;
+                    }
                 }
             }
         } else {
@@ -771,7 +740,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
                 const double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
                 const double slack = 1e-12 * (fmin(fabs(tn), 1e300) + fmin(fabs(tf), 1e300)) + 1e-300;
                 near_[c] = tn;
-                hit_[c] = tn <= tf + slack && tn <= hi && tf + slack >= 0.0;
+                hit_[c] = tn <= tf + slack && tn <= hi && (rec || tf + slack >= 0.0);
             }
             if (hit_[0] && hit_[1]) {
                 const bool swap = near_[1] < near_[0];
@@ -781,6 +750,15 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
             } else {
                 cur = hit_[0] ? c0 : (hit_[1] ? c1 : NONE);
             }
+        }
+    }
+    if (rec) {  // the mesh's entries into stream order (insertion sort: there are seldom more than two)
+        for (int a = n_before + 1; a < w.n; a++) {
+            const double ta = cb.t_at(a);
+            const uint32_t pa = cb.pos_at(a), ca = cb.cls_at(a);
+            int b = a - 1;
+            while (b >= n_before && cb.pos_at(b) > pa) { cb.put(b + 1, cb.t_at(b), cb.pos_at(b), cb.cls_at(b)); b--; }
+            cb.put(b + 1, ta, pa, ca);
         }
     }
 }
@@ -837,15 +815,15 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             double t0, t1;
             bool hit = box_intersect(ray, u0[2], u0[3], u0[4], u0[5], u0[6], u0[7], t0, t1);
             if (count) flops += F_BOX;
-            if (CULL && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
+            if (CULL && kind == K_GROUP && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             uint32_t next = hit ? i + 1 : w1;
             if constexpr (CULL) {
                 bool in_csg = false;
                 if constexpr (HAS_CSG) in_csg = cs_top > 0;
-                if (hit && (w0 & MESH_BIT) && !(Buf::enabled && record) && !in_csg) {
+                if (hit && (w0 & MESH_BIT) && !in_csg) {
                     bool any_hit = false;
                     if constexpr (!Buf::enabled) any_hit = cb.any_hit;
-                    mesh_walk(S, ray, i, w2, w3, w, any_hit, flops, count);
+                    mesh_walk(S, ray, i, w2, w3, w, record, cb, any_hit, flops, count);
                     next = w1;
                 }
             }
@@ -1365,7 +1343,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // Lightable::intensity_at of one shade point for every light (light/point.rs:27-38,
 // light/area.rs:75-90): one closest-hit shadow ray per light sample (World::is_shadowed,
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
-template <bool HAS_CSG, bool PER_LANE>
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
                      uint32_t& flops, uint32_t& err, uint32_t& n_shadow) {
     if (__ballot(on) == 0ull) return;
@@ -1393,11 +1371,11 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             // A point light behind the surface: Material::lighting takes neither diffuse nor specular
             // from it (light_dot_normal < 0, material.rs:70-83, the same expression as in k_shade), so
             // whatever is_shadowed answers is multiplied by zero.  The ray still counts as cast.
-            const bool moot = !is_area && dot(sr.d, normal) < 0.0;
+            const bool moot = CULL && !is_area && dot(sr.d, normal) < 0.0;
             const bool cast = on && !moot;
-            Walk w = walk_init_below(distance);
+            Walk w = CULL ? walk_init_below(distance) : walk_init();
             if (__ballot(cast) != 0ull) {
-                walk_tree<HAS_CSG, true, PER_LANE>(S, sr, cast, false, w, NoRecord{(S.flags & 2u) != 0}, flops, true, err);
+                walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0}, flops, true, err);
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
             }
             bool shadowed = moot;  // reported as intensity 0: k_shade then skips the light's loop as well
@@ -1415,7 +1393,8 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
 
 // colour_at for every ray of one level, minus the shading and the recursion
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool SHADOWS>
+// Without CULL every walk is the reference's, test for test (a slow mode the others are checked against).
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool SHADOWS, bool CULL = true>
 __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -1437,11 +1416,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
-    // a lane-walked tree and few rays: one wave per ray (see traverse<ONE_RAY>)
-    const bool few = PER_LANE && !PRIMARY && n_rays <= (record ? FEW_RAYS : FEW_RAYS_RUNS);
-    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
-                             : few   ? (n_rays + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64)
-                                     : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64) : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
     uint32_t parity = 0;
     for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x, parity ^= 1u) {
     LOOP_FENCE();
@@ -1468,7 +1443,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
             A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
         }
     } else {
-        uint32_t idx = few ? step * (TRACE_BLOCK / 64) + wave_in_block : step * TRACE_BLOCK + threadIdx.x;
+        uint32_t idx = step * TRACE_BLOCK + threadIdx.x;
         on = idx < n_rays;
         rec_idx = rec_base + (on ? idx : 0);
         ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
@@ -1478,16 +1453,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    if constexpr (PER_LANE && !PRIMARY) {
-        if (few) {
-            traverse<HAS_CSG, true, RecordBuf, true>(S, ray, on, record, w, buf, flops, lane == 0, err);
-            on = on && lane == 0;  // one lane finishes the ray
-        } else {
-            walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
-        }
-    } else {
-        walk_tree<HAS_CSG, true, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
-    }
+    walk_tree<HAS_CSG, CULL, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -1603,7 +1569,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
     if constexpr (SHADOWS) {
         Rng none;
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
+        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
     }
 #if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
     {
@@ -1641,7 +1607,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
 
 // The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
 // whole chunk first (area lights); otherwise k_trace casts them itself.
-template <bool HAS_CSG, bool PER_LANE>
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
@@ -1659,7 +1625,7 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevS
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
         const V3 normal = mk(A.R.nx[rec_idx], A.R.ny[rec_idx], A.R.nz[rec_idx]);
-        intensities<HAS_CSG, PER_LANE>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
+        intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
@@ -2289,7 +2255,7 @@ struct rt_scene {
     int device = 0;
     Workspace ws[MAX_STREAMS];
     int n_streams = 2;
-    int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane
+    int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane, 3: the reference's walk
     uint32_t grid_blocks = 4096;        // blocks of every level kernel (they stride over the rays)
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
@@ -2371,9 +2337,16 @@ struct FirstLevel {   // where the first level's rays come from
 // shadow walk behind each of them doubles the serial chain, while k_shadow runs all the chunk's
 // shadow rays side by side.
 bool uses_lane_walk(const rt_scene* s) { return s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS); }
-bool fused_shadows(const rt_scene* s, bool per_lane) { return !s->has_area && !per_lane; }
+bool reference_walk(const rt_scene* s) { return s->traversal == 3; }  // no device-only shortcut anywhere
+bool fused_shadows(const rt_scene* s, bool per_lane) { return !s->has_area && !per_lane && !reference_walk(s); }
 template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
 void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
+    if constexpr (HAS_CSG && !PER_LANE) {
+        if (reference_walk(s)) {
+            hipLaunchKernelGGL((k_trace<PRIMARY, true, false, false, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+            return;
+        }
+    }
     if (fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
     else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
 }
@@ -2456,7 +2429,14 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         }
     }
 
-    if (!fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
+    bool shadows_queued = false;
+    if constexpr (HAS_CSG && !PER_LANE) {
+        if (reference_walk(s)) {
+            hipLaunchKernelGGL((k_shadow<true, false, false>), grid, block, 0, st, s->dev, A);
+            shadows_queued = true;
+        }
+    }
+    if (!shadows_queued && !fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
@@ -2474,6 +2454,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
 int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
                          double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
     const bool per_lane = uses_lane_walk(s);
+    if (reference_walk(s)) return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
     if (s->has_csg) {
         if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
         return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
@@ -2665,7 +2646,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 uint32_t tri = d->leaf_tri[leaf];
                 rec[4] = id;
                 rec[5] = tri;
-                rec[6] = 0;  // filled below: how many sibling triangles of the same mesh matrix follow directly
                 for (int k = 0; k < 9; k++) recd[4 + k] = d->tri_data[(size_t)tri * 18 + k];
                 for (int k = 0; k < 9; k++) tri_normals[(size_t)tri * 9 + k] = d->tri_data[(size_t)tri * 18 + 9 + k];
             } else {
@@ -2686,25 +2666,6 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rec[1] = unit_of[d->node_skip[i]];
             rec[2] = csg ? d->node_arg[i] : 0;
             for (int k = 0; k < 6; k++) recd[2 + k] = d->node_bbox[(size_t)i * 6 + k];
-        }
-    }
-
-    // runs of sibling triangles: node i+1 is the next sibling of leaf i exactly when it lies in the
-    // same parent, i.e. no enclosing subtree ends at i+1
-    {
-        std::vector<uint32_t> parent_end(d->n_nodes, d->n_nodes), stack_end;
-        for (uint32_t i = 0; i < d->n_nodes; i++) {
-            while (!stack_end.empty() && stack_end.back() <= i) stack_end.pop_back();
-            parent_end[i] = stack_end.empty() ? d->n_nodes : stack_end.back();
-            if (d->node_kind[i] != RT_NODE_LEAF) stack_end.push_back(d->node_skip[i]);
-        }
-        for (uint32_t i = d->n_nodes; i-- > 0;) {
-            if (d->node_kind[i] != RT_NODE_LEAF || d->leaf_shape[d->node_arg[i]] != RT_TRIANGLE) continue;
-            uint32_t* rec = &stream[(size_t)unit_of[i] * 16];
-            uint32_t j = i + 1;
-            if (j < d->n_nodes && j < parent_end[i] && d->node_kind[j] == RT_NODE_LEAF &&
-                d->leaf_shape[d->node_arg[j]] == RT_TRIANGLE && stream[(size_t)unit_of[j] * 16 + 4] == rec[4])
-                rec[6] = stream[(size_t)unit_of[j] * 16 + 6] + 1;
         }
     }
 
@@ -2870,7 +2831,7 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
             }
             return RT_OK;
         case RT_OPT_TRAVERSAL:
-            if (value > 2) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave) or 2 (lane)");
+            if (value > 3) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave), 2 (lane) or 3 (reference)");
             s->traversal = (int)value;
             return RT_OK;
         case RT_OPT_MIN_CHUNKS:

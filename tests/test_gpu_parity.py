@@ -181,3 +181,109 @@ def test_error_paths():
     assert e.value.code == ra.RT_ERR_NAN
     with pytest.raises(RuntimeError):
         ol.OracleScene.from_file(os.path.join(ROOT, "scenes", "chapter8.yaml")).colour_at(ray, 5)
+
+
+def _create_from_arrays(d):
+    """rt_scene_create straight from (possibly edited) rt_scene_desc arrays; returns (handle, keepalive)."""
+    keep = {k: np.ascontiguousarray(v) for k, v in d.items() if isinstance(v, np.ndarray)}
+    sd = ra.SceneDesc()
+
+    def p(name, ctype):
+        a = keep[name]
+        return a.ctypes.data_as(C.POINTER(ctype)) if a.size else C.POINTER(ctype)()
+    sd.n_nodes = len(keep["node_kind"])
+    sd.node_kind, sd.node_skip, sd.node_arg = p("node_kind", C.c_uint32), p("node_skip", C.c_uint32), p("node_arg", C.c_uint32)
+    sd.node_bbox = p("node_bbox", C.c_double)
+    sd.n_leaves = len(keep["leaf_shape"])
+    sd.leaf_shape, sd.leaf_inv, sd.leaf_param = p("leaf_shape", C.c_uint32), p("leaf_inv", C.c_double), p("leaf_param", C.c_double)
+    sd.leaf_tri, sd.leaf_class, sd.leaf_material = p("leaf_tri", C.c_uint32), p("leaf_class", C.c_uint32), p("leaf_material", C.c_uint32)
+    sd.leaf_casts_shadow = p("leaf_casts_shadow", C.c_uint8)
+    sd.n_tris, sd.tri_data = len(keep["tri_data"]), p("tri_data", C.c_double)
+    sd.n_csgs, sd.csg_op = len(keep["csg_op"]), p("csg_op", C.c_uint32)
+    sd.n_classes, sd.csg_left_bits = int(d["n_classes"]), p("csg_left_bits", C.c_uint64)
+    sd.n_materials, sd.material, sd.material_pattern = len(keep["material"]), p("material", C.c_double), p("material_pattern", C.c_uint32)
+    sd.n_patterns = len(keep["pat_kind"])
+    sd.pat_kind, sd.pat_a, sd.pat_b = p("pat_kind", C.c_uint32), p("pat_a", C.c_uint32), p("pat_b", C.c_uint32)
+    sd.pat_inv, sd.pat_colour = p("pat_inv", C.c_double), p("pat_colour", C.c_double)
+    sd.n_lights = len(keep["light_kind"])
+    sd.light_kind, sd.light_data, sd.light_steps = p("light_kind", C.c_uint32), p("light_data", C.c_double), p("light_steps", C.c_uint32)
+    h = C.c_void_p()
+    rc = ra.hip_lib().rt_scene_create(C.byref(sd), C.byref(h))
+    assert rc == 0, ra.hip_lib().rt_last_error().decode()
+    return h, (keep, sd)
+
+
+@pytest.mark.parametrize("scene,scale,root_depth", [("scenes/chapter15.yaml", 0.2, 0), ("scenes/bounding-box.yaml", 0.15, 1)])
+def test_mesh_hierarchy_respects_the_stored_boxes(scene, scale, root_depth):
+    """A group's stored box decides whether its children are tested at all (group/mod.rs:30-32).
+    The walk through a mesh's own hierarchy must drop exactly the intersections the reference's
+    walk never makes.  With the reference's boxes that only happens on a box's rim; here every
+    box inside a mesh is shrunk on purpose, so triangles stick out of their groups' boxes by the
+    thousand: the frame must still equal, bit for bit, the one made with the reference's walk
+    (traversal 3: no device-only shortcut), and differ from the frame of the untouched scene."""
+    g, _ = pair(scene, scale)
+    d = g.desc()
+    lib = ra.hip_lib()
+    cam = g.camera_ptr()
+    W, H = g.width, g.height
+
+    def frame(desc, mode):
+        h, keep = _create_from_arrays(desc)
+        assert lib.rt_set_option(h, ra.OPT_TRAVERSAL, mode) == 0
+        rgb = np.zeros((H, W, 3))
+        st = ra.Stats()
+        rc = lib.rt_render(h, cam, 5, None, None, rgb.ctypes.data_as(C.c_void_p), None, 0, C.byref(st))
+        assert rc == 0, lib.rt_last_error().decode()
+        lib.rt_scene_destroy(h)
+        return rgb, st.as_dict()
+
+    a0, _ = frame(d, 3)
+    b0, _ = frame(d, 2)
+    assert np.array_equal(a0.view(np.uint64), b0.view(np.uint64))
+    # shrink the box of every group below a mesh's root
+    kind, skip = d["node_kind"], d["node_skip"]
+    depth_of = np.zeros(len(kind), dtype=np.int64)
+    open_ = []
+    for i in range(len(kind)):
+        while open_ and skip[open_[-1]] <= i:
+            open_.pop()
+        depth_of[i] = len(open_)
+        if kind[i] != 0:
+            open_.append(i)
+    bb = d["node_bbox"].copy()
+    inner = (kind == 1) & (depth_of > root_depth) & np.isfinite(bb).all(axis=1)
+    assert inner.sum() > 10
+    with np.errstate(invalid="ignore"):
+        c = 0.5 * (bb[:, :3] + bb[:, 3:])
+        e = 0.5 * (bb[:, 3:] - bb[:, :3])
+    bb[inner, :3] = (c - 0.7 * e)[inner]
+    bb[inner, 3:] = (c + 0.7 * e)[inner]
+    d2 = dict(d)
+    d2["node_bbox"] = bb
+    a1, sa = frame(d2, 3)
+    b1, sb = frame(d2, 2)
+    assert np.array_equal(a1.view(np.uint64), b1.view(np.uint64))
+    assert sa["shade_hits"] == sb["shade_hits"] and sa["secondary_rays"] == sb["secondary_rays"]
+    assert not np.array_equal(a0, a1)
+
+
+@pytest.mark.parametrize("scene,scale,depth", [
+    ("scenes/chapter11.yaml", 1.0, 30), ("scenes/chapter11-water.yaml", 0.5, 5), ("scenes/chapter13.yaml", 0.5, 5),
+    ("scenes/chapter14.yaml", 0.5, 5), (None, 0.5, 20), ("scenes/chapter15-dragon.yaml", 0.3, 5),
+    ("scenes/chapter16.yaml", 1.0, 5), ("scenes/bounding-box.yaml", 0.3, 5), ("scenes/area-light.yaml", 0.3, 5)])
+def test_shortcuts_do_not_change_the_image(scene, scale, depth):
+    """Everything the device adds to the reference's walk (bounding-sphere and distance culling,
+    the meshes' own hierarchies, shadow rays that stop at the light or at their first hit or are
+    not cast at all) must leave every f64 of the frame as the reference's walk computes it, at
+    sizes beyond what the CPU oracle renders in a test."""
+    frames = []
+    for mode in (3, 0):
+        g, _ = pair(scene, scale)
+        g.set_option(ra.OPT_TRAVERSAL, mode)
+        seeds = g.row_seeds()
+        frames.append(g.render(depth, seeds))
+    (a, sa), (b, sb) = frames
+    assert np.array_equal(a.pixels.view(np.uint64), b.pixels.view(np.uint64))
+    assert np.array_equal(a.rgb8, b.rgb8)
+    for key in ("secondary_rays", "shadow_rays", "shade_hits"):
+        assert sa[key] == sb[key], key
