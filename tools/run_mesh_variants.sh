@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/run_mesh_variants.sh name...
+# usage: tools/run_mesh_variants.sh name...
 cp raytracer_amd/librt_hip.so /tmp/librt_hip_orig.so
 for name in "$@"; do
   cp variants/librt_hip_$name.so raytracer_amd/librt_hip.so
