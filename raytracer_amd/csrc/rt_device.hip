@@ -411,7 +411,8 @@ struct RecordBuf {
 // light is culled like anything beyond a hit.  World::is_shadowed (world.rs:117-123) asks whether
 // the closest hit casts a shadow and lies before the light; a closest hit at or beyond the light
 // answers no, as does finding nothing.  When every leaf of the scene casts a shadow the first hit
-// found before the light already settles it: with `any_hit` the lane stops walking there.
+// found before the light already settles it: with `any_hit` a lane that walks on its own stops
+// there (the wave-uniform walk does not look: the test costs its loop more than it saves).
 struct NoRecord {
     bool any_hit;
     static constexpr bool enabled = false;
@@ -511,9 +512,6 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     for (;;) {
         if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
         if (i >= n) break;
-        if constexpr (!Buf::enabled) {
-            if (cb.any_hit && w.pos < LIMIT) skip_until = NONE;
-        }
         bool act = skip_until <= i;
         if (__ballot(act) == 0ull) {
             i = wave_min_u32(skip_until);
