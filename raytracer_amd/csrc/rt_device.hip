@@ -66,6 +66,12 @@ constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one st
 #ifndef SHADOW_WAVES
 #define SHADOW_WAVES 5    // the same for k_shadow
 #endif
+#ifndef LANE_TRACE_WAVES
+#define LANE_TRACE_WAVES 4   // k_trace / k_shadow when every lane walks on its own
+#endif
+#ifndef LANE_SHADOW_WAVES
+#define LANE_SHADOW_WAVES 4
+#endif
 #ifndef SHADE_WAVES
 #define SHADE_WAVES 3     // and for k_shade
 #endif
@@ -133,6 +139,7 @@ struct Ray { V3 o, d; };
 //       per matrix, not once per triangle) and its vertex normals in `tri_normals`.
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 constexpr uint32_t MESH_BIT = 1u << 12;  // group header w0: the subtree is a mesh with a hierarchy of its own (w2 root, w3 matrix)
+constexpr uint32_t NESTED_BIT = 1u << 13;  // group inside a mesh: its box lies within the box of every group up to the mesh's root
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
     uint32_t n_materials, n_patterns;
@@ -150,7 +157,7 @@ struct DevScene {
     const double* light;        // n_lights*12
     const uint32_t* light_meta; // n_lights*4: kind, usteps, vsteps, 0
     const double* bvh;          // 16 f64 per inner node of the mesh hierarchies (see mesh_walk)
-    const uint32_t* bvh_tris;   // unit positions of the triangles of the hierarchies' leaves
+    const double* bvh_tris;     // 10 f64 per triangle of the hierarchies' leaves: p1, e1, e2, unit position (low word)
     const uint32_t* parent;     // n_units: unit position of the enclosing group / csg, NONE at the top
 };
 
@@ -649,32 +656,37 @@ constexpr int BVH_STACK = 64;
 constexpr uint32_t BVH_LEAF = 0x80000000u;  // reference to a leaf: BVH_LEAF | (count - 1) << 27 | first entry of bvh_tris
 
 // Does the ray pass the stored boxes of the groups strictly between unit position `pos` and `root`?
-DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32_t pos, uint32_t root) {
+// `mag` bounds the magnitude of the root box's coordinates per axis.  A hit point well inside a
+// box (by a margin far above the rounding of either computation) passes the reference's test for
+// it; when that box is NESTED it also lies well inside every box further up, which ends the climb.
+// Otherwise the reference's own test decides, level by level.
+DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32_t pos, uint32_t root, V3 mag) {
     const V3 P = ray.o + ray.d * t;
+    const double mx = 1e-9 * (mag.x + fabs(ray.o.x) + fabs(P.x));
+    const double my = 1e-9 * (mag.y + fabs(ray.o.y) + fabs(P.y));
+    const double mz = 1e-9 * (mag.z + fabs(ray.o.z) + fabs(P.z));
     uint32_t g = S.parent[pos];
     for (int k = 0; k < BVH_STACK && g != root && g != NONE; k++) {
-        const double* b = (const double*)(S.stream + (size_t)g * 16);
+        const uint32_t* hdr = S.stream + (size_t)g * 16;
+        const double* b = (const double*)hdr;
+        const uint32_t gw0 = hdr[0], up = S.parent[g];
         const double x0 = b[2], y0 = b[3], z0 = b[4], x1 = b[5], y1 = b[6], z1 = b[7];
-        // a hit point well inside the box (margin far above the rounding of either computation)
-        // settles it; otherwise the reference's test decides
-        const double mx = 1e-9 * (fabs(x0) + fabs(x1) + fabs(ray.o.x) + fabs(P.x));
-        const double my = 1e-9 * (fabs(y0) + fabs(y1) + fabs(ray.o.y) + fabs(P.y));
-        const double mz = 1e-9 * (fabs(z0) + fabs(z1) + fabs(ray.o.z) + fabs(P.z));
         const bool inside = t > 0.0 && P.x > x0 + mx && P.x < x1 - mx && P.y > y0 + my && P.y < y1 - my && P.z > z0 + mz &&
                             P.z < z1 - mz;
+        if (inside && (gw0 & NESTED_BIT)) return true;
         if (!inside) {
             double ta, tb;
             if (!box_intersect(ray, x0, y0, z0, x1, y1, z1, ta, tb)) return false;
         }
-        g = S.parent[g];
+        g = up;
     }
     return true;
 }
 
 // One lane's ray against a mesh.  `ray` is the world-space ray.
 template <class Buf>
-DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, Walk& w, bool record,
-                   Buf cb, bool any_hit, uint32_t& flops, bool count) {
+DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, V3 mag, Walk& w,
+                   bool record, Buf cb, bool any_hit, uint32_t& flops, bool count) {
     const bool rec = Buf::enabled && record;
     const int n_before = w.n;
     const double* m = S.xform + (size_t)xf * 12;
@@ -699,17 +711,20 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
         if (cur & BVH_LEAF) {
             const uint32_t at = cur & 0x07FFFFFFu, left = (cur >> 27) & 15u;
             cur = left ? (BVH_LEAF | ((left - 1u) << 27) | (at + 1u)) : NONE;
-            const uint32_t pos = S.bvh_tris[at];
-            const uint32_t* lr = S.stream + (size_t)pos * 16;
-            const double* ld = (const double*)lr;
+            const double* ld = S.bvh_tris + (size_t)at * 10;
+            double td[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) td[k] = ld[k];
+            const uint32_t pos = (uint32_t)__double2loint(td[9]);
             double t, u, v;
-            const bool got = triangle_hit(r, mk(ld[4], ld[5], ld[6]), mk(ld[7], ld[8], ld[9]), mk(ld[10], ld[11], ld[12]), t, u, v);
+            const bool got = triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
             if (count) flops += F_XFORM + F_TRI;
             if (got) {
                 if (t != t) w.nan_seen = true;
                 w.arrival++;
                 const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
-                if ((t > 0.0 || rec) && below && mesh_ancestors_pass(S, ray, t, pos, root_pos)) {
+                if ((t > 0.0 || rec) && below && mesh_ancestors_pass(S, ray, t, pos, root_pos, mag)) {
+                    const uint32_t* lr = S.stream + (size_t)pos * 16;
                     if (rec) {
                         if (w.n < cb.cap()) { cb.put(w.n, t, pos, lr[3]); w.n++; } else w.overflow = true;
                     }
@@ -821,7 +836,9 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                 if (hit && (w0 & MESH_BIT) && !in_csg) {
                     bool any_hit = false;
                     if constexpr (!Buf::enabled) any_hit = cb.any_hit;
-                    mesh_walk(S, ray, i, w2, w3, w, record, cb, any_hit, flops, count);
+                    const V3 mag = mk(2.0 * fmax(fabs(u0[2]), fabs(u0[5])), 2.0 * fmax(fabs(u0[3]), fabs(u0[6])),
+                                      2.0 * fmax(fabs(u0[4]), fabs(u0[7])));
+                    mesh_walk(S, ray, i, w2, w3, mag, w, record, cb, any_hit, flops, count);
                     next = w1;
                 }
             }
@@ -1393,7 +1410,7 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
 // (world.rs:33-49,129-177; intersection/mod.rs:45-109).
 // Without CULL every walk is the reference's, test for test (a slow mode the others are checked against).
 template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool SHADOWS, bool CULL = true>
-__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
     if (A.counters->error & 1u) return;  // an earlier level ran out of records: the chunk is retried
@@ -1606,7 +1623,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : TRACE_WAVES) void k_trac
 // The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
 // whole chunk first (area lights); otherwise k_trace casts them itself.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
-__global__ __launch_bounds__(256, HAS_CSG ? 2 : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
     const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
@@ -2098,7 +2115,7 @@ bool bounding_sphere(uint32_t shape, const double* inv, double mn, double mx, do
 
 // ---- the meshes' own hierarchies (see mesh_walk)
 struct MeshTri { double lo[3], hi[3], c[3]; uint32_t pos; };
-struct MeshBuild { std::vector<double> nodes; std::vector<uint32_t> tris; };
+struct MeshBuild { std::vector<double> nodes; std::vector<double> tris; const uint32_t* stream; };
 constexpr uint32_t MESH_MIN_TRIS = 4, MESH_LEAF_TRIS = 4;
 
 void mesh_bounds(const MeshTri* t, size_t n, double* lo, double* hi) {
@@ -2116,9 +2133,15 @@ double half_area(const double* lo, const double* hi) {
 uint32_t mesh_build(std::vector<MeshTri>& t, size_t b, size_t e, int depth, MeshBuild& out) {
     const size_t n = e - b;
     if (n <= MESH_LEAF_TRIS) {
-        uint32_t at = (uint32_t)out.tris.size();
+        uint32_t at = (uint32_t)(out.tris.size() / 10);
         std::sort(t.begin() + b, t.begin() + e, [](const MeshTri& x, const MeshTri& y) { return x.pos < y.pos; });
-        for (size_t k = b; k < e; k++) out.tris.push_back(t[k].pos);
+        for (size_t k = b; k < e; k++) {
+            const double* v = (const double*)(out.stream + (size_t)t[k].pos * 16) + 4;  // p1, e1, e2
+            out.tris.insert(out.tris.end(), v, v + 9);
+            double tail = 0.0;
+            std::memcpy(&tail, &t[k].pos, 4);
+            out.tris.push_back(tail);
+        }
         return BVH_LEAF | ((uint32_t)(n - 1) << 27) | at;
     }
     double clo[3] = {HUGE_VAL, HUGE_VAL, HUGE_VAL}, chi[3] = {-HUGE_VAL, -HUGE_VAL, -HUGE_VAL};
@@ -2671,6 +2694,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     // leaves are all triangles under one matrix
     std::vector<uint32_t> parent_unit((size_t)units + 4, NONE);
     MeshBuild meshes;
+    meshes.stream = stream.data();
     {
         std::vector<uint32_t> parent_node(d->n_nodes, NONE), open;
         for (uint32_t i = 0; i < d->n_nodes; i++) {
@@ -2728,6 +2752,18 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rec[2] = mesh_build(tris, 0, tris.size(), 0, meshes);
             rec[3] = matrix[i];
             rec[0] |= MESH_BIT;
+            // groups whose box lies within the box of every group up to the root (always, for boxes
+            // that Group::bounding_box made); parents come first, so one pass settles the chain
+            for (uint32_t j = i + 1; j < d->node_skip[i]; j++) {
+                if (d->node_kind[j] != RT_NODE_GROUP) continue;
+                const uint32_t par = parent_node[j];
+                const double* bj = d->node_bbox + (size_t)j * 6;
+                const double* bp = d->node_bbox + (size_t)par * 6;
+                bool within = true;
+                for (int a = 0; a < 3; a++) within = within && bj[a] >= bp[a] && bj[3 + a] <= bp[3 + a];
+                const bool par_ok = par == i || (stream[(size_t)unit_of[par] * 16] & NESTED_BIT);
+                if (within && par_ok) stream[(size_t)unit_of[j] * 16] |= NESTED_BIT;
+            }
         }
     }
 
