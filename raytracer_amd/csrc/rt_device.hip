@@ -139,11 +139,13 @@ struct Ray { V3 o, d; };
 //       per matrix, not once per triangle) and its vertex normals in `tri_normals`.
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 constexpr uint32_t MESH_BIT = 1u << 12;  // group header w0: the subtree is a mesh with a hierarchy of its own (w2 root, w3 matrix)
+constexpr uint32_t MESH_ALL_CAST = 1u << 14, MESH_NONE_CAST = 1u << 15;  // mesh root: every / no triangle casts a shadow
 constexpr uint32_t NESTED_BIT = 1u << 13;  // group inside a mesh: its box lies within the box of every group up to the mesh's root
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
     uint32_t n_materials, n_patterns;
-    uint32_t flags;             // bit0: some material has a nonzero transparency; bit1: shadow rays may stop at their first hit
+    uint32_t flags;             // bit0: some material has a nonzero transparency; bit1: shadow rays may stop at their first
+                                // hit; bit2: shadow rays walk twice (see NoRecord)
     const uint32_t* stream;
     const double* xform;        // n_xforms*12
     const double* tri_normals;  // n_tris*9
@@ -405,6 +407,7 @@ struct RecordBuf {
     ContBuf fast, big;
     static constexpr bool enabled = true;
     static constexpr bool any_hit = false;
+    static constexpr uint32_t filter = 0;
     DEV int cap() const { return big.cap; }
     DEV void put(int k, double tt, uint32_t p, uint32_t c) const {
         if (k < fast.cap) fast.put(k, tt, p, c); else big.put(k, tt, p, c);
@@ -420,8 +423,14 @@ struct RecordBuf {
 // answers no, as does finding nothing.  When every leaf of the scene casts a shadow the first hit
 // found before the light already settles it: with `any_hit` a lane that walks on its own stops
 // there (the wave-uniform walk does not look: the test costs its loop more than it saves).
+// A scene where nearly everything casts a shadow but not all of it (a glass case around a mesh) gets
+// two walks per shadow ray instead: the first only takes leaves that cast none and finds the
+// closest of them before the light; the second only takes leaves that do, starts from that result
+// and stops at the first hit that beats it - there is one iff the closest hit of all casts a
+// shadow.  `filter`: 0 every leaf, 1 only leaves that cast no shadow, 2 only leaves that cast one.
 struct NoRecord {
     bool any_hit;
+    uint32_t filter;
     static constexpr bool enabled = false;
     DEV int cap() const { return 0; }
     DEV void put(int, double, uint32_t, uint32_t) const {}
@@ -688,6 +697,8 @@ template <class Buf>
 DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, V3 mag, Walk& w,
                    bool record, Buf cb, bool any_hit, uint32_t& flops, bool count) {
     const bool rec = Buf::enabled && record;
+    uint32_t filter = 0;
+    if constexpr (!Buf::enabled) filter = cb.filter;
     const int n_before = w.n;
     const double* m = S.xform + (size_t)xf * 12;
     Ray r;
@@ -723,8 +734,9 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
                 if (t != t) w.nan_seen = true;
                 w.arrival++;
                 const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
-                if ((t > 0.0 || rec) && below && mesh_ancestors_pass(S, ray, t, pos, root_pos, mag)) {
-                    const uint32_t* lr = S.stream + (size_t)pos * 16;
+                const uint32_t* lr = S.stream + (size_t)pos * 16;
+                const bool wanted = filter == 0 || (((lr[0] >> 8) & 1u) != 0) == (filter == 2u);
+                if ((t > 0.0 || rec) && below && wanted && mesh_ancestors_pass(S, ray, t, pos, root_pos, mag)) {
                     if (rec) {
                         if (w.n < cb.cap()) { cb.put(w.n, t, pos, lr[3]); w.n++; } else w.overflow = true;
                     }
@@ -791,9 +803,15 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
     int clen = 0, cs_top = 0;
     (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
     auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t lmat) {
+        if constexpr (!Buf::enabled) {
+            // a filtered shadow walk: the other kind of leaf does not exist; a walk that starts from
+            // another walk's result can meet an equal t at an earlier position, which sorts first
+            if (cb.filter) on = on && (((lw0 >> 8) & 1u) != 0) == (cb.filter == 2u);
+        }
         if (on) {
             if (tt != tt) w.nan_seen = true;
-            const bool below = w.pos == NONE || tt < w.t;
+            bool below = w.pos == NONE || tt < w.t;
+            if constexpr (!Buf::enabled) below = below || (cb.filter == 2u && tt == w.t && p < w.pos && w.pos < LIMIT);
             if constexpr (Buf::enabled) {
                 if (record && below) {
                     if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
@@ -809,7 +827,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
     for (;;) {
         if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
         if constexpr (!Buf::enabled) {
-            if (cb.any_hit && w.pos < LIMIT) i = n;
+            if (cb.any_hit && w.pos < LIMIT && ((w.w0 >> 8) & 1u)) i = n;
         }
         const bool act = i < n;
         if (__ballot(act) == 0ull) break;
@@ -833,7 +851,11 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             if constexpr (CULL) {
                 bool in_csg = false;
                 if constexpr (HAS_CSG) in_csg = cs_top > 0;
-                if (hit && (w0 & MESH_BIT) && !in_csg) {
+                bool skip_mesh = false;
+                if constexpr (!Buf::enabled)
+                    skip_mesh = (cb.filter == 1u && (w0 & MESH_ALL_CAST)) || (cb.filter == 2u && (w0 & MESH_NONE_CAST));
+                if (hit && (w0 & MESH_BIT) && !in_csg && skip_mesh) next = w1;
+                if (hit && (w0 & MESH_BIT) && !in_csg && !skip_mesh) {
                     bool any_hit = false;
                     if constexpr (!Buf::enabled) any_hit = cb.any_hit;
                     const V3 mag = mk(2.0 * fmax(fabs(u0[2]), fabs(u0[5])), 2.0 * fmax(fabs(u0[3]), fabs(u0[6])),
@@ -1390,7 +1412,15 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             const bool cast = on && !moot;
             Walk w = CULL ? walk_init_below(distance) : walk_init();
             if (__ballot(cast) != 0ull) {
-                walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0}, flops, true, err);
+                if (CULL && PER_LANE && (S.flags & 4u)) {
+                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{false, 1u}, flops, true, err);
+                    bool nan_seen = w.nan_seen && w.arrival >= 2;
+                    w.nan_seen = false; w.arrival = 0;
+                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{true, 2u}, flops, true, err);
+                    if (nan_seen) err |= 4u;
+                } else {
+                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0, 0u}, flops, true, err);
+                }
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
             }
             bool shadowed = moot;  // reported as intensity 0: k_shade then skips the light's loop as well
@@ -2752,6 +2782,14 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rec[2] = mesh_build(tris, 0, tris.size(), 0, meshes);
             rec[3] = matrix[i];
             rec[0] |= MESH_BIT;
+            bool all_cast = true, none_cast = true;
+            for (uint32_t j = i + 1; j < d->node_skip[i]; j++) {
+                if (d->node_kind[j] != RT_NODE_LEAF) continue;
+                const bool casts = d->leaf_casts_shadow[d->node_arg[j]] != 0;
+                all_cast = all_cast && casts;
+                none_cast = none_cast && !casts;
+            }
+            rec[0] |= (all_cast ? MESH_ALL_CAST : 0u) | (none_cast ? MESH_NONE_CAST : 0u);
             // groups whose box lies within the box of every group up to the root (always, for boxes
             // that Group::bounding_box made); parents come first, so one pass settles the chain
             for (uint32_t j = i + 1; j < d->node_skip[i]; j++) {
@@ -2822,6 +2860,10 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         // the wave finishes together anyway, and there the work counters keep describing the
         // reference's full walk.
         if (all_cast && units > PER_LANE_MIN_UNITS) s->dev.flags |= 2u;
+        // nearly everything casts a shadow: two filtered walks (see NoRecord) beat one full one
+        uint32_t n_dark = 0;
+        for (uint32_t i = 0; i < d->n_leaves; i++) n_dark += d->leaf_casts_shadow[i] ? 0u : 1u;
+        if (!all_cast && units > PER_LANE_MIN_UNITS && (uint64_t)n_dark * 20 <= d->n_leaves) s->dev.flags |= 4u;
     }
     UP(stream, stream); UP(xforms, xform); UP(tri_normals, tri_normals); UP(cull, cull); UP(csg_op, csg_op); UP(csg_bits, csg_bits);
     UP(mat, mat); UP(pat_meta, pat_meta); UP(pat_inv, pat_inv); UP(pat_col, pat_col); UP(light, light);

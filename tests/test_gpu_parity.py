@@ -213,7 +213,7 @@ def _create_from_arrays(d):
     return h, (keep, sd)
 
 
-@pytest.mark.parametrize("scene,scale,root_depth", [("scenes/chapter15.yaml", 0.2, 0), ("scenes/bounding-box.yaml", 0.15, 1)])
+@pytest.mark.parametrize("scene,scale,root_depth", [("scenes/chapter15.yaml", 0.2, 0), ("scenes/bounding-box.yaml", 0.15, 2)])
 def test_mesh_hierarchy_respects_the_stored_boxes(scene, scale, root_depth):
     """A group's stored box decides whether its children are tested at all (group/mod.rs:30-32).
     The walk through a mesh's own hierarchy must drop exactly the intersections the reference's
