@@ -1945,21 +1945,47 @@ __global__ __launch_bounds__(256) void k_order_assign(Recs R, uint32_t base, uin
     if (ct != NONE && R.hit_pos[ct] != NONE) R.order[ct] = next;
     R.order[rec] = mine;
 }
-// (4) one lane per row: step the row's generator, leaving its state at every shade point
-__global__ __launch_bounds__(64) void k_rng_rows(Rng* states, const uint32_t* row_base, const uint32_t* row_total,
-                                                 const unsigned long long* seeds, uint32_t rows, uint32_t chunk_row0,
-                                                 uint32_t part_block, uint32_t part_rank, uint32_t part_world,
-                                                 uint32_t draws) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+// (4) the generator state at every shade point.  Shade point k of a row starts k * draws steps
+// after the row's seed, and the state transition of xoshiro256 is linear over GF(2) (the ++ only
+// scrambles the output), so that state is T^(draws * k) applied to the seeded state: a product of
+// the precomputed matrices jump[b] = T^(draws * 2^b) over the set bits b of k.  A matrix is stored
+// by columns, 4 words each; applying it XORs the columns selected by the state's bits.  One block
+// per row; stepping the generator along the row instead takes one lane 15 ms for 320 000 steps.
+constexpr uint32_t RNG_JUMPS = 26;  // shade points per row < 2^26
+__global__ __launch_bounds__(256) void k_rng_rows(Rng* states, const uint32_t* row_base, const uint32_t* row_total,
+                                                  const unsigned long long* seeds, uint32_t rows, uint32_t chunk_row0,
+                                                  uint32_t part_block, uint32_t part_rank, uint32_t part_world,
+                                                  const unsigned long long* jump) {
+    const uint32_t row = blockIdx.x;
     if (row >= rows) return;
     uint32_t local = chunk_row0 + row, gy = local;
     if (part_world > 1) gy = ((local / part_block) * part_world + part_rank) * part_block + local % part_block;
-    Rng r = rng_seed(seeds[gy]);
-    uint32_t n = row_total[row];
+    const Rng seeded = rng_seed(seeds[gy]);
+    const uint32_t n = row_total[row];
     Rng* out = states + row_base[row];
-    for (uint32_t k = 0; k < n; k++) {
-        out[k] = r;
-        for (uint32_t d = 0; d < draws; d++) (void)rng_next(r);
+    for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) {
+        const uint32_t k = k0 + threadIdx.x;
+        unsigned long long v[4] = {seeded.s0, seeded.s1, seeded.s2, seeded.s3};
+        for (uint32_t b = 0; b < RNG_JUMPS; b++) {
+            const bool mine = k < n && ((k >> b) & 1u);
+            if (__ballot(mine) == 0ull) continue;
+            const unsigned long long* col = jump + (size_t)b * 1024;
+            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+            for (int wd = 0; wd < 4; wd++) {
+                for (int bit = 0; bit < 64; bit++) {
+                    const unsigned long long m = 0ull - ((v[wd] >> bit) & 1ull);
+                    const unsigned long long* c = col + (size_t)(wd * 64 + bit) * 4;
+                    a0 ^= c[0] & m; a1 ^= c[1] & m; a2 ^= c[2] & m; a3 ^= c[3] & m;
+                }
+            }
+            if (mine) { v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
+        }
+        if (k < n) {
+            Rng r;
+            r.s0 = v[0]; r.s1 = v[1]; r.s2 = v[2]; r.s3 = v[3];
+            out[k] = r;
+        }
     }
 }
 
@@ -2143,6 +2169,51 @@ bool bounding_sphere(uint32_t shape, const double* inv, double mn, double mx, do
     return true;
 }
 
+// ---- jump matrices of the area lights' generator (see k_rng_rows)
+struct Gf2Matrix { uint64_t col[256][4]; };   // column j = image of the state with only bit j set
+void gf2_apply(const Gf2Matrix& m, const uint64_t* v, uint64_t* out) {
+    uint64_t a[4] = {0, 0, 0, 0};
+    for (int j = 0; j < 256; j++)
+        if ((v[j >> 6] >> (j & 63)) & 1ull)
+            for (int w = 0; w < 4; w++) a[w] ^= m.col[j][w];
+    for (int w = 0; w < 4; w++) out[w] = a[w];
+}
+void gf2_mul(const Gf2Matrix& a, const Gf2Matrix& b, Gf2Matrix& out) {  // out = a * b (first b, then a)
+    Gf2Matrix r;
+    for (int j = 0; j < 256; j++) gf2_apply(a, b.col[j], r.col[j]);
+    out = r;
+}
+// T^(draws * 2^b) for b = 0 .. RNG_JUMPS-1, 1024 words each, where T is one step of xoshiro256's
+// state (rand_xoshiro 0.6.0: s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1_old << 17; s3 = rotl(s3, 45)).
+std::vector<unsigned long long> rng_jump_matrices(uint64_t draws) {
+    auto step = [](uint64_t* s) {
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = (s[3] << 45) | (s[3] >> 19);
+    };
+    std::vector<Gf2Matrix> m(3);  // 0: T^(2^i), 1: accumulated power, 2: scratch
+    Gf2Matrix &sq = m[0], &acc = m[1];
+    for (int j = 0; j < 256; j++) {
+        uint64_t e[4] = {0, 0, 0, 0};
+        e[j >> 6] = 1ull << (j & 63);
+        for (int w = 0; w < 4; w++) acc.col[j][w] = e[w];  // identity
+        step(e);
+        for (int w = 0; w < 4; w++) sq.col[j][w] = e[w];
+    }
+    for (uint64_t d = draws; d; d >>= 1) {
+        if (d & 1) gf2_mul(sq, acc, acc);
+        if (d >> 1) gf2_mul(sq, sq, sq);
+    }
+    std::vector<unsigned long long> out((size_t)RNG_JUMPS * 1024);
+    for (uint32_t b = 0; b < RNG_JUMPS; b++) {
+        for (int j = 0; j < 256; j++)
+            for (int w = 0; w < 4; w++) out[(size_t)b * 1024 + (size_t)j * 4 + w] = acc.col[j][w];
+        if (b + 1 < RNG_JUMPS) gf2_mul(acc, acc, acc);
+    }
+    return out;
+}
+
 // ---- the meshes' own hierarchies (see mesh_walk)
 struct MeshTri { double lo[3], hi[3], c[3]; uint32_t pos; };
 struct MeshBuild { std::vector<double> nodes; std::vector<double> tris; const uint32_t* stream; };
@@ -2302,6 +2373,7 @@ struct rt_scene {
     DevScene dev{};
     std::vector<void*> allocations;
     bool has_csg = false, has_area = false;
+    unsigned long long* rng_jump = nullptr;  // area lights: the jump matrices of k_rng_rows
     bool shade_lds = false;             // the tables k_shade looks things up in fit in LDS
     int device = 0;
     Workspace ws[MAX_STREAMS];
@@ -2461,7 +2533,11 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
             HIP_TRY(hipMemcpyAsync(totals.data(), w.row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             uint64_t acc = 0;
-            for (uint32_t r = 0; r < rows; r++) { bases[r] = (uint32_t)acc; acc += totals[r]; }
+            for (uint32_t r = 0; r < rows; r++) {
+                bases[r] = (uint32_t)acc;
+                acc += totals[r];
+                if (totals[r] >> RNG_JUMPS) return fail(RT_ERR_CAPACITY, "too many shade points in one image row");
+            }
             if (acc > 0xFFFFFFF0ull) return fail(RT_ERR_CAPACITY, "too many shade points in one chunk");
             HIP_TRY(hipMemcpyAsync(w.row_base, bases.data(), rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));  // `bases` goes out of scope
@@ -2471,10 +2547,10 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
                 if (lv[level].n)
                     hipLaunchKernelGGL(k_order_assign, dim3((lv[level].n + 255) / 256), block, 0, st, w.R, lv[level].base,
                                        lv[level].n, width, w.pixel_base, w.row_base, level == 0 ? 1 : 0);
-            hipLaunchKernelGGL(k_rng_rows, dim3((rows + 63) / 64), dim3(64), 0, st, w.rng_states, w.row_base, w.row_total,
+            hipLaunchKernelGGL(k_rng_rows, dim3(rows), dim3(256), 0, st, w.rng_states, w.row_base, w.row_total,
                                first.seeds, rows, first.primary ? base.chunk_row0 : 0u,
                                first.primary ? base.part_block : 0u, first.primary ? base.part_rank : 0u,
-                               first.primary ? base.part_world : 1u, s->dev.draws_per_shade);
+                               first.primary ? base.part_world : 1u, s->rng_jump);
             HIP_TRY(hipGetLastError());
             A.rng_states = w.rng_states;
         }
@@ -2870,6 +2946,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     UP(light_meta, light_meta);
     UP(meshes.nodes, bvh); UP(meshes.tris, bvh_tris); UP(parent_unit, parent);
 #undef UP
+    if (has_area) {
+        const std::vector<unsigned long long> jump = rng_jump_matrices(draws);
+        rc = upload(jump, &s->rng_jump);
+        if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+        keep(s->rng_jump);
+    }
     *out = s;
     return RT_OK;
 }
