@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1..4)")
     ap.add_argument("--grid-blocks", type=int, default=None)
-    ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane")
+    ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane, 3 the reference walk (no device-only shortcut)")
     ap.add_argument("--chunk-pixels", type=int, default=None)
     args = ap.parse_args()
 

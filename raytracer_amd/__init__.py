@@ -284,7 +284,8 @@ class Scene:
         return host_lib().rth_device_scene(self.h)
 
     def set_option(self, option, value):
-        """rt_set_option on the uploaded scene (OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS)."""
+        """rt_set_option on the uploaded scene (OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS,
+        OPT_TRAVERSAL: 0 auto, 1 wave walk, 2 lane walk, 3 the reference's walk; OPT_MIN_CHUNKS)."""
         rc = hip_lib().rt_set_option(self.upload(), option, value)
         if rc != RT_OK:
             raise RtError(rc, hip_lib().rt_last_error().decode())

@@ -19,9 +19,11 @@
 //
 // The tree is a depth-first stream of 64-byte units with skip links.  Small trees are walked by
 // the 64 lanes of a wave together (position in an SGPR, node data through scalar loads, a
-// per-lane "skip until" for rejected subtrees); large ones (meshes) lane by lane.  Intersections
-// arrive in the reference's insertion order, so a strict `<` against the running best reproduces
-// its stable sort + first-positive-t rule without sorting.
+// per-lane "skip until" for rejected subtrees); large ones lane by lane, and a mesh inside them
+// by a hierarchy of its own (mesh_walk).  Intersections arrive in the reference's insertion
+// order (ties inside a mesh go to the lower stream position, which is the same thing), so a
+// strict `<` against the running best reproduces its stable sort + first-positive-t rule
+// without sorting.
 //
 // Scenes with area lights take a deferred route, because the reference threads one rng stream
 // through a whole image row in depth-first order: the level kernels only trace (ray paths never
