@@ -287,3 +287,69 @@ def test_shortcuts_do_not_change_the_image(scene, scale, depth):
     assert np.array_equal(a.rgb8, b.rgb8)
     for key in ("secondary_rays", "shadow_rays", "shade_hits"):
         assert sa[key] == sb[key], key
+
+
+def test_coincident_triangles_resolve_like_the_reference_list():
+    """Every triangle of the teapot is doubled: leaf 2k+1 becomes a copy of leaf 2k with another
+    material, so each hit is an exact tie in t between two leaves.  The reference's stable sort
+    keeps the earlier leaf (world.rs:90-106, intersection/list.rs:24-50); the walk through the
+    mesh's own hierarchy meets the two in any order and must pick the same one."""
+    g, _ = pair("scenes/chapter15.yaml", 0.2)
+    d = g.desc()
+    lib = ra.hip_lib()
+    tri_leaves = np.nonzero(d["leaf_shape"] == 5)[0]
+    pairs = len(tri_leaves) // 2
+    even, odd = tri_leaves[0:2 * pairs:2], tri_leaves[1:2 * pairs:2]
+    d2 = dict(d)
+    tri = d["tri_data"].copy()
+    tri[d["leaf_tri"][odd]] = tri[d["leaf_tri"][even]]
+    d2["tri_data"] = tri
+    # a second material: the first triangle's with a solid green pattern
+    m0 = d["leaf_material"][even[0]]
+    d2["pat_kind"] = np.append(d["pat_kind"], np.uint32(0))
+    d2["pat_a"] = np.append(d["pat_a"], np.uint32(0xFFFFFFFF))
+    d2["pat_b"] = np.append(d["pat_b"], np.uint32(0xFFFFFFFF))
+    d2["pat_inv"] = np.vstack([d["pat_inv"], np.array([[1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0]], dtype=np.float64)])
+    d2["pat_colour"] = np.vstack([d["pat_colour"], np.array([[0.0, 1.0, 0.0]])])
+    d2["material"] = np.vstack([d["material"], d["material"][m0:m0 + 1]])
+    d2["material_pattern"] = np.append(d["material_pattern"], np.uint32(len(d["pat_kind"])))
+    lm = d["leaf_material"].copy()
+    lm[odd] = len(d["material"])
+    d2["leaf_material"] = lm
+    frames = []
+    for mode in (3, 2, 1):
+        h, keep = _create_from_arrays(d2)
+        assert lib.rt_set_option(h, ra.OPT_TRAVERSAL, mode) == 0
+        rgb = np.zeros((g.height, g.width, 3))
+        rc = lib.rt_render(h, g.camera_ptr(), 5, None, None, rgb.ctypes.data_as(C.c_void_p), None, 0, None)
+        assert rc == 0, lib.rt_last_error().decode()
+        lib.rt_scene_destroy(h)
+        frames.append(rgb)
+    assert np.array_equal(frames[0].view(np.uint64), frames[1].view(np.uint64))
+    assert np.array_equal(frames[0].view(np.uint64), frames[2].view(np.uint64))
+    # which leaf wins shows: with the materials of each pair exchanged the frame is another one
+    lm2 = d["leaf_material"].copy()
+    lm2[even] = len(d["material"])
+    d3 = dict(d2)
+    d3["leaf_material"] = lm2
+    h, keep = _create_from_arrays(d3)
+    rgb = np.zeros((g.height, g.width, 3))
+    assert lib.rt_render(h, g.camera_ptr(), 5, None, None, rgb.ctypes.data_as(C.c_void_p), None, 0, None) == 0
+    lib.rt_scene_destroy(h)
+    assert (rgb != frames[0]).any(axis=2).mean() > 0.01
+
+
+def test_area_light_rows_keep_their_generators_under_a_partition():
+    """Each image row has its own generator (camera.rs:143-161) and every shade point's state is
+    reached by jumping from the row's seed: rendering the rows in interleaved blocks on two or
+    three ranks must reproduce the whole frame bit for bit."""
+    g, _ = pair("scenes/area-light.yaml", 0.25)
+    seeds = g.row_seeds()
+    whole, _ = g.render(5, seeds)
+    for world in (2, 3):
+        frame = np.zeros_like(whole.pixels)
+        for rank in range(world):
+            part = ra.Partition(8, rank, world)
+            c, _ = g.render(5, seeds, part)
+            frame[ra.local_rows(g.height, part)] = c.pixels
+        assert np.array_equal(frame.view(np.uint64), whole.pixels.view(np.uint64))
