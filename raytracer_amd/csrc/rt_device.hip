@@ -1463,7 +1463,18 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
-    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64) : (n_rays + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    // A lane-walked level with few rays spreads them over more waves (`lanes` active lanes in each, a
+    // power of two): lanes of one wave at different kinds of node take turns, so a wave's walk costs
+    // the sum of its lanes' branches, and such a level lasts as long as its slowest wave.
+    uint32_t lanes = 64;
+    if constexpr (PER_LANE && !PRIMARY) {
+#ifndef SPREAD_WAVES
+#define SPREAD_WAVES 4096u
+#endif
+        while (lanes > 1 && n_rays <= (lanes / 2) * SPREAD_WAVES) lanes >>= 1;
+    }
+    const uint32_t rays_per_step = (TRACE_BLOCK / 64) * lanes;
+    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64) : (n_rays + rays_per_step - 1) / rays_per_step;
     uint32_t parity = 0;
     for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x, parity ^= 1u) {
     LOOP_FENCE();
@@ -1490,8 +1501,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
             A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
         }
     } else {
-        uint32_t idx = step * TRACE_BLOCK + threadIdx.x;
-        on = idx < n_rays;
+        uint32_t idx = step * rays_per_step + wave_in_block * lanes + lane;
+        on = lane < lanes && idx < n_rays;
         rec_idx = rec_base + (on ? idx : 0);
         ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
         ray.d = mk(A.R.dx[rec_idx], A.R.dy[rec_idx], A.R.dz[rec_idx]);
