@@ -1931,17 +1931,31 @@ __global__ __launch_bounds__(256) void k_order_sizes(Recs R, uint32_t base, uint
     }
     R.order[rec] = s;
 }
-// (2) one lane per row: running offsets of the row's pixels; row_total[row] = shade points in the row
-__global__ __launch_bounds__(64) void k_order_rows(Recs R, uint32_t width, uint32_t rows, uint32_t* pixel_base,
-                                                   uint32_t* row_total) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+// (2) one block per row: running offsets of the row's pixels; row_total[row] = shade points in the row
+__global__ __launch_bounds__(256) void k_order_rows(Recs R, uint32_t width, uint32_t rows, uint32_t* pixel_base,
+                                                    uint32_t* row_total) {
+    const uint32_t row = blockIdx.x;
     if (row >= rows) return;
-    uint32_t acc = 0;
-    for (uint32_t x = 0; x < width; x++) {
+    __shared__ uint32_t s_sum[256];
+    // every thread takes a run of consecutive pixels; the runs' sums are scanned through LDS
+    const uint32_t per = (width + 255) / 256;
+    const uint32_t x0 = min(threadIdx.x * per, width), x1 = min(x0 + per, width);
+    uint32_t mine = 0;
+    for (uint32_t x = x0; x < x1; x++) mine += R.order[(size_t)row * width + x];
+    s_sum[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? s_sum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_sum[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t acc = s_sum[threadIdx.x] - mine;
+    for (uint32_t x = x0; x < x1; x++) {
         pixel_base[(size_t)row * width + x] = acc;
         acc += R.order[(size_t)row * width + x];
     }
-    row_total[row] = acc;
+    if (threadIdx.x == 255) row_total[row] = s_sum[255];
 }
 // (3) top-down: order = position of the shade point in the chunk's state array
 __global__ __launch_bounds__(256) void k_order_assign(Recs R, uint32_t base, uint32_t n, uint32_t width,
@@ -1986,9 +2000,11 @@ __global__ __launch_bounds__(256) void k_rng_rows(Rng* states, const uint32_t* r
             unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
             for (int wd = 0; wd < 4; wd++) {
-                for (int bit = 0; bit < 64; bit++) {
+#pragma unroll 16
+                for (int bit = 0; bit < 64; bit++) {  // unrolled: the column loads are scalar and should overlap
                     const unsigned long long m = 0ull - ((v[wd] >> bit) & 1ull);
-                    const unsigned long long* c = col + (size_t)(wd * 64 + bit) * 4;
+                    // wave-uniform address: through the constant address space these are scalar loads
+                    const CADDR unsigned long long* c = (const CADDR unsigned long long*)(uintptr_t)(col + (size_t)(wd * 64 + bit) * 4);
                     a0 ^= c[0] & m; a1 ^= c[1] & m; a2 ^= c[2] & m; a3 ^= c[3] & m;
                 }
             }
@@ -2540,7 +2556,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
             if (rc == RT_OK) rc = grow(&w.row_total, &w.row_cap, (size_t)rows);
             if (rc == RT_OK) rc = grow(&w.row_base, &w.row_base_cap, (size_t)rows);
             if (rc != RT_OK) return rc;
-            hipLaunchKernelGGL(k_order_rows, dim3((rows + 63) / 64), dim3(64), 0, st, w.R, width, rows, w.pixel_base,
+            hipLaunchKernelGGL(k_order_rows, dim3(rows), dim3(256), 0, st, w.R, width, rows, w.pixel_base,
                                w.row_total);
             std::vector<uint32_t> totals(rows), bases(rows);
             HIP_TRY(hipMemcpyAsync(totals.data(), w.row_total, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
