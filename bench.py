@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--grid-blocks", type=int, default=None)
     ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane, 3 the reference walk (no device-only shortcut)")
     ap.add_argument("--chunk-pixels", type=int, default=None)
+    ap.add_argument("--min-chunks", type=int, default=None, help="cut a frame of a megapixel or more into at least this many chunks")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +97,8 @@ def main():
         scene.set_option(ra.OPT_TRAVERSAL, args.traversal)
     if args.chunk_pixels:
         scene.set_option(ra.OPT_CHUNK_PIXELS, args.chunk_pixels)
+    if args.min_chunks:
+        scene.set_option(ra.OPT_MIN_CHUNKS, args.min_chunks)
     W, H = scene.width, scene.height
     part = multi.partition_for(rank, world) if world > 1 else None
     rows = len(ra.local_rows(H, part))

@@ -214,9 +214,10 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  * Tuning knobs of a scene's renderer (no counterpart in the reference; the
  * defaults suit a 288 GB MI355X).  Results do not depend on them.
  *   RT_OPT_STREAMS         1..4: image-row chunks in flight at once (default 2)
- *   RT_OPT_CHUNK_PIXELS    pixels per chunk (default 16 Mi, and at least four chunks
- *                          for a frame of a megapixel or more); a chunk is whole rows,
- *                          a multiple of 8 of them
+ *   RT_OPT_CHUNK_PIXELS    most pixels in a chunk (default 26 Mi, less when the record
+ *                          arrays would not fit the device's memory); a chunk is
+ *                          whole rows, a multiple of 8 of them, and a frame is cut
+ *                          into equal chunks, a multiple of the stream count
  *   RT_OPT_RECS_PER_PIXEL  ray records reserved per pixel of a chunk (default
  *                          24); a chunk that needs more is split and retried
  *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 4096)
@@ -226,8 +227,8 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *                          own); 3: the reference's walk, test for test, with none
  *                          of the device-only shortcuts (slow; what the other
  *                          three are checked against)
- *   RT_OPT_MIN_CHUNKS      a frame of a megapixel or more is cut into at least this
- *                          many chunks (default 4)
+ *   RT_OPT_MIN_CHUNKS      a frame of two megapixels or more is cut into at least
+ *                          this many chunks (default 2)
  */
 enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4,
        RT_OPT_TRAVERSAL = 5, RT_OPT_MIN_CHUNKS = 6 };

@@ -2412,9 +2412,9 @@ struct rt_scene {
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
-    size_t chunk_pixels = (size_t)16 << 20;
+    size_t chunk_pixels = (size_t)26 << 20;
     size_t recs_per_pixel = 24;
-    uint32_t min_chunks = 4;
+    uint32_t min_chunks = 2;
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
 };
@@ -3076,17 +3076,28 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     // row chunks: multiples of 8 rows, at most chunk_pixels pixels.  Each pass queues every
     // pending chunk (alternating over the workspaces so two chunks overlap on the GPU), then
     // waits; chunks whose rays did not fit their record arrays are split and go round again.
-    uint32_t chunk_rows = (uint32_t)std::max<size_t>(8, (s->chunk_pixels / W) & ~(size_t)7);
-    if ((size_t)rows * W >= ((size_t)1 << 20)) {
-        // at least min_chunks chunks for a frame of a megapixel or more, so that all streams stay busy
-        // (a rank of a multi-GPU job only renders its share of the rows)
-        uint32_t share = ((rows + s->min_chunks - 1) / s->min_chunks + 7) & ~7u;
-        chunk_rows = std::max(8u, std::min(chunk_rows, share));
+    // As few and as large chunks as fit (a level of many rays runs closer to the kernels' peak than
+    // several small ones), but at least min_chunks for a frame of two megapixels or more, so that
+    // one chunk's k_shade launches run beside the next one's k_trace, and a multiple of the
+    // number of streams, so that the streams end together.  The record arrays of all workspaces
+    // may take 80 % of the device's memory.
+    const int n_ws = std::max(1, std::min(s->n_streams, MAX_STREAMS));
+    size_t chunk_px = std::max<size_t>(s->chunk_pixels, 64);
+    {
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total) {
+            const size_t per_px = s->recs_per_pixel * (REC_BYTES + 8 * (size_t)s->dev.n_lights);
+            chunk_px = std::max<size_t>(std::min(chunk_px, mem_total / 10 * 8 / ((size_t)n_ws * per_px)), (size_t)8 * W);
+        }
     }
+    const size_t frame_px = (size_t)rows * W;
+    size_t n_chunks = (frame_px + chunk_px - 1) / chunk_px;
+    if (frame_px >= ((size_t)2 << 20)) n_chunks = std::max<size_t>(n_chunks, s->min_chunks);
+    if (n_chunks > 1) n_chunks = (n_chunks + n_ws - 1) / n_ws * n_ws;
+    uint32_t chunk_rows = std::max(8u, (uint32_t)(((rows + n_chunks - 1) / n_chunks + 7) & ~(size_t)7));
     struct Job { uint32_t r0, nr; };
     std::vector<Job> pending;
     for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0)});
-    const int n_ws = std::max(1, std::min(s->n_streams, MAX_STREAMS));
     while (!pending.empty()) {
         std::vector<Job> queued[MAX_STREAMS];
         size_t max_px = 0;
