@@ -3080,14 +3080,17 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     // several small ones), but at least min_chunks for a frame of two megapixels or more, so that
     // one chunk's k_shade launches run beside the next one's k_trace, and a multiple of the
     // number of streams, so that the streams end together.  The record arrays of all workspaces
-    // may take 80 % of the device's memory.
+    // may take 80 % of the device's memory, and 90 % of what is free of it.
     const int n_ws = std::max(1, std::min(s->n_streams, MAX_STREAMS));
     size_t chunk_px = std::max<size_t>(s->chunk_pixels, 64);
     {
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total) {
-            const size_t per_px = s->recs_per_pixel * (REC_BYTES + 8 * (size_t)s->dev.n_lights);
-            chunk_px = std::max<size_t>(std::min(chunk_px, mem_total / 10 * 8 / ((size_t)n_ws * per_px)), (size_t)8 * W);
+            const size_t per_rec = REC_BYTES + 8 * (size_t)s->dev.n_lights, per_px = s->recs_per_pixel * per_rec;
+            size_t held = 0;  // what this scene's workspaces hold already counts as available
+            for (int k = 0; k < n_ws; k++) held += s->ws[k].rec_cap * per_rec;
+            const size_t budget = std::min(mem_total / 10 * 8, (mem_free + held) / 10 * 9);
+            chunk_px = std::max<size_t>(std::min(chunk_px, budget / ((size_t)n_ws * per_px)), (size_t)8 * W);
         }
     }
     const size_t frame_px = (size_t)rows * W;
