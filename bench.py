@@ -221,6 +221,19 @@ def main():
                         "achieved_GBs_over_frame": alg_bytes / (ms_per_step * 1e-3) / 1e9,
                         "peak_GBs": HBM_PEAK_GBS},
             }
+            if stats["mesh_nodes"]:
+                # lane-walked meshes: what the walks fetch from the meshes' own hierarchies (128 B per node
+                # visited, 80 B per triangle tested), over the time of the kernels that walk
+                walk_ms = stats["ms_trace"] + stats["ms_shadow"]
+                mesh_bytes = 128 * stats["mesh_nodes"] + 80 * stats["mesh_tris"]
+                out["roofline"]["mesh_fetch"] = {
+                    "nodes_per_frame": stats["mesh_nodes"], "triangles_per_frame": stats["mesh_tris"],
+                    "nodes_per_ray": stats["mesh_nodes"] / max(1, primary + secondary + shadow),
+                    "triangles_per_ray": stats["mesh_tris"] / max(1, primary + secondary + shadow),
+                    "bytes_per_frame": mesh_bytes,
+                    "achieved_GBs": mesh_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
+                    "note": "served by the L2 / Infinity Cache (the hierarchies are a few MB), so a latency figure, not an HBM one",
+                }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity_on_sample"] = cpu_baseline(args, scene_file, scale, depth, frame, H)
         print(json.dumps(out), flush=True)

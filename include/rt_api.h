@@ -161,6 +161,9 @@ typedef struct rt_stats {
     uint64_t flop_light;
     uint64_t fused_shadows;  /* 1: k_trace cast the shadow rays itself and ms_shadow
                                 is 0; 0: k_shadow did (area lights, meshes)        */
+    uint64_t mesh_nodes;     /* nodes of the meshes' own hierarchies visited (128 bytes
+                                fetched each) and triangles tested in their leaves  */
+    uint64_t mesh_tris;      /* (80 bytes each), by all rays of the frame           */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

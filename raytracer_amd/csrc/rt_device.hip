@@ -373,6 +373,12 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
 //    that sorts before the hit.  Only an intersection below the running best can
 //    do so (an equal t that arrives later sorts after the hit), so the walk
 //    records those and the caller drops the ones that the final hit undercut.
+// What a lane's walks add to the statistics: algorithmic FLOP (`+=` takes those), and for the
+// meshes' own hierarchies the nodes visited and triangles tested (their fetches: 128 and 80 bytes).
+struct Work {
+    uint32_t flops, nodes, tris;
+    DEV Work& operator+=(uint32_t f) { flops += f; return *this; }
+};
 struct Walk {
     double t;              // closest hit so far
     uint32_t pos;          // unit position of the hit leaf's record, or NONE
@@ -494,7 +500,7 @@ DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uin
 // change the closest hit or what sorts before it (w.arrival then no longer counts every
 // intersection of the reference's list; rt_probe, which reports that count, walks without it).
 template <bool HAS_CSG, bool CULL, class Buf>
-DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                   bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
     const uint32_t n = S.n_units;
@@ -697,7 +703,7 @@ DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32
 // One lane's ray against a mesh.  `ray` is the world-space ray.
 template <class Buf>
 DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, V3 mag, Walk& w,
-                   bool record, Buf cb, bool any_hit, uint32_t& flops, bool count) {
+                   bool record, Buf cb, bool any_hit, Work& flops, bool count) {
     const bool rec = Buf::enabled && record;
     uint32_t filter = 0;
     if constexpr (!Buf::enabled) filter = cb.filter;
@@ -731,7 +737,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
             const uint32_t pos = (uint32_t)__double2loint(td[9]);
             double t, u, v;
             const bool got = triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
-            if (count) flops += F_XFORM + F_TRI;
+            if (count) { flops += F_XFORM + F_TRI; flops.tris++; }
             if (got) {
                 if (t != t) w.nan_seen = true;
                 w.arrival++;
@@ -754,7 +760,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
 #pragma unroll
             for (int k = 0; k < 12; k++) b[k] = nd[k];
             const uint32_t c0 = (uint32_t)__double2loint(nd[12]), c1 = (uint32_t)__double2hiint(nd[12]);
-            if (count) flops += 2 * F_BOX;
+            if (count) { flops += 2 * F_BOX; flops.nodes++; }
             double near_[2];
             bool hit_[2];
 #pragma unroll
@@ -795,7 +801,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
 // loads, so a lane only pays for the boxes and leaves its own ray reaches.  Lanes at different
 // kinds of node take turns within an iteration.
 template <bool HAS_CSG, bool CULL, class Buf>
-DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                        bool count, uint32_t& err) {
     const uint32_t n = S.n_units;
     double ct[HAS_CSG ? CSG_CAP : 1];
@@ -941,7 +947,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
 // Chooses the walk: small trees are walked by the wave together (scalar loads, no divergence),
 // large ones lane by lane.
 template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf>
-DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, uint32_t& flops,
+DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                    bool count, uint32_t& err) {
     if constexpr (PER_LANE) traverse_lane<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
     else traverse<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
@@ -1045,13 +1051,13 @@ struct Counters {
 struct LevelState { uint32_t n, base; };
 struct ChunkStatus {
     uint32_t error, total_recs, levels, pad;
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light;  // this chunk's statistics
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;  // this chunk's statistics
 };
 // Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
 // and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
 constexpr uint32_t STAT_SHARDS = 256;
 struct __attribute__((aligned(64))) StatShard {
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, pad[2];
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;
 #ifdef RT_PHASE_TIMERS
     unsigned long long phase[8];  // shader-clock ticks per k_trace phase, summed over waves
 #endif
@@ -1384,7 +1390,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
-                     uint32_t& flops, uint32_t& err, uint32_t& n_shadow) {
+                     Work& flops, uint32_t& err, uint32_t& n_shadow) {
     if (__ballot(on) == 0ull) return;
     for (uint32_t l = 0; l < S.n_lights; l++) {
         const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
@@ -1461,7 +1467,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
     buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
-    uint32_t flops = 0, err = 0, n_shade = 0, n_spawned = 0, flops_shadow = 0, n_shadow = 0;
+    Work flops{}, flops_shadow{};
+    uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
     // A lane-walked level with few rays spreads them over more waves (`lanes` active lanes in each, a
     // power of two): lanes of one wave at different kinds of node take turns, so a wave's walk costs
@@ -1643,8 +1650,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
 
     // statistics: one atomic per wave and counter
     uint32_t s_shade = wave_sum_u32(n_shade), s_spawned = wave_sum_u32(n_spawned);
-    uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
+    uint32_t s_flops_lo = wave_sum_u32(flops.flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops.flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
+    if constexpr (PER_LANE) {
+        const uint32_t s_nodes = wave_sum_u32(flops.nodes + flops_shadow.nodes), s_tris = wave_sum_u32(flops.tris + flops_shadow.tris);
+        if (lane == 0 && (s_nodes | s_tris)) {
+            StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
+            atomicAdd(&st->mesh_nodes, (unsigned long long)s_nodes);
+            atomicAdd(&st->mesh_tris, (unsigned long long)s_tris);
+        }
+    }
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
         if (s_spawned) atomicAdd(&st->secondary, (unsigned long long)s_spawned);
@@ -1653,7 +1668,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     }
     if constexpr (SHADOWS) {
         uint32_t s_shadow = wave_sum_u32(n_shadow);
-        uint32_t sh_lo = wave_sum_u32(flops_shadow & 0xFFFFu), sh_hi = wave_sum_u32(flops_shadow >> 16);
+        uint32_t sh_lo = wave_sum_u32(flops_shadow.flops & 0xFFFFu), sh_hi = wave_sum_u32(flops_shadow.flops >> 16);
         if (lane == 0) {
             StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
             if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
@@ -1670,7 +1685,8 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
     const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
-    uint32_t flops = 0, err = 0, n_shadow = 0;
+    Work flops{};
+    uint32_t err = 0, n_shadow = 0;
     for (uint32_t first = blockIdx.x * 256; first < total; first += gridDim.x * 256) {
         LOOP_FENCE();
         const uint32_t idx = first + threadIdx.x;
@@ -1686,8 +1702,16 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
         intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     uint32_t s_shadow = wave_sum_u32(n_shadow);
-    uint32_t s_flops_lo = wave_sum_u32(flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops >> 16);
+    uint32_t s_flops_lo = wave_sum_u32(flops.flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops.flops >> 16);
     unsigned long long any_err = __ballot(err != 0);
+    if constexpr (PER_LANE) {
+        const uint32_t s_nodes = wave_sum_u32(flops.nodes), s_tris = wave_sum_u32(flops.tris);
+        if (lane == 0 && (s_nodes | s_tris)) {
+            StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
+            atomicAdd(&st->mesh_nodes, (unsigned long long)s_nodes);
+            atomicAdd(&st->mesh_tris, (unsigned long long)s_tris);
+        }
+    }
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
         if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
@@ -1894,13 +1918,15 @@ __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n
 // STAT_SHARDS threads.
 __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* levels, uint32_t n_levels,
                                                            const Counters* counters, StatShard* stats, ChunkStatus* out) {
-    __shared__ unsigned long long sums[6];
-    if (threadIdx.x < 6) sums[threadIdx.x] = 0ull;
+    __shared__ unsigned long long sums[8];
+    if (threadIdx.x < 8) sums[threadIdx.x] = 0ull;
     __syncthreads();
     StatShard* st = stats + threadIdx.x;
     atomicAdd(&sums[0], st->secondary); atomicAdd(&sums[1], st->shadow); atomicAdd(&sums[2], st->shade);
     atomicAdd(&sums[3], st->flop_trace); atomicAdd(&sums[4], st->flop_shadow); atomicAdd(&sums[5], st->flop_light);
+    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris);
     st->secondary = 0; st->shadow = 0; st->shade = 0; st->flop_trace = 0; st->flop_shadow = 0; st->flop_light = 0;
+    st->mesh_nodes = 0; st->mesh_tris = 0;
     __syncthreads();
     if (threadIdx.x != 0) return;
     uint32_t used = 0;
@@ -1912,6 +1938,7 @@ __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* lev
     out->pad = 0;
     out->secondary = sums[0]; out->shadow = sums[1]; out->shade = sums[2];
     out->flop_trace = sums[3]; out->flop_shadow = sums[4]; out->flop_light = sums[5];
+    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7];
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
@@ -2027,7 +2054,8 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     Ray ray;
     ray.o = mk(R.ox[q], R.oy[q], R.oz[q]);
     ray.d = mk(R.dx[q], R.dy[q], R.dz[q]);
-    uint32_t flops = 0, err = 0;
+    Work flops{};
+    uint32_t err = 0;
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
     int inside = 0;
     double n1 = 1.0, n2 = 1.0;
@@ -2471,7 +2499,7 @@ void free_workspace(Workspace& w) {
 }
 
 struct RunTotals {
-    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0;
+    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0, mesh_nodes = 0, mesh_tris = 0;
     uint64_t trace_launches = 0;
     uint32_t levels = 0;
     double ms_trace = 0, ms_shadow = 0, ms_shade = 0;
@@ -2640,6 +2668,7 @@ int collect(Workspace& w, size_t n_slots, std::vector<ChunkStatus>& out, RunTota
 void add_stats(RunTotals& tot, const ChunkStatus& c) {
     tot.secondary += c.secondary; tot.shadow += c.shadow; tot.shade += c.shade;
     tot.flop_trace += c.flop_trace; tot.flop_shadow += c.flop_shadow; tot.flop_light += c.flop_light;
+    tot.mesh_nodes += c.mesh_nodes; tot.mesh_tris += c.mesh_tris;
     tot.levels = std::max(tot.levels, c.levels);
 }
 
@@ -3180,6 +3209,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->flop_trace = tot.flop_trace;
         stats->flop_shadow = tot.flop_shadow;
         stats->flop_light = tot.flop_light;
+        stats->mesh_nodes = tot.mesh_nodes;
+        stats->mesh_tris = tot.mesh_tris;
         stats->fused_shadows = fused_shadows(s, uses_lane_walk(s)) ? 1 : 0;
     }
     return RT_OK;
