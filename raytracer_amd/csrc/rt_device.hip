@@ -2431,6 +2431,7 @@ struct rt_scene {
     std::vector<void*> allocations;
     bool has_csg = false, has_area = false;
     unsigned long long* rng_jump = nullptr;  // area lights: the jump matrices of k_rng_rows
+    bool spawns = true;  // some material reflects or refracts; without one every level but the first stays empty
     bool shade_lds = false;             // the tables k_shade looks things up in fit in LDS
     int device = 0;
     Workspace ws[MAX_STREAMS];
@@ -2985,8 +2986,12 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     s->dev.class_words = (uint32_t)words;
     s->dev.draws_per_shade = (uint32_t)draws;
     s->dev.flags = 0;
-    for (uint32_t i = 0; i < d->n_materials; i++)
+    s->spawns = false;
+    for (uint32_t i = 0; i < d->n_materials; i++) {
         if (d->material[(size_t)i * 7 + 5] != 0.0) s->dev.flags |= 1u;
+        // reflected_colour / refracted_colour spawn for reflective > 0 and |transparency| > EPSILON (world.rs:129-177)
+        if (d->material[(size_t)i * 7 + 4] > 0.0 || !(std::fabs(d->material[(size_t)i * 7 + 5]) <= EPS)) s->spawns = true;
+    }
     {
         bool all_cast = true;
         for (uint32_t i = 0; i < d->n_leaves; i++) all_cast = all_cast && d->leaf_casts_shadow[i] != 0;
@@ -3071,6 +3076,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     if (p.world > 1 && (p.block_rows == 0 || p.block_rows % 8 != 0 || p.rank >= p.world))
         return fail(RT_ERR_INVALID, "partition needs block_rows a multiple of 8 and rank < world");
     if (s->has_area && !row_seeds) return fail(RT_ERR_INVALID, "a scene with an area light needs the per-row seeds");
+    if (!s->spawns) depth = 0;  // no ray is ever spawned: the deeper levels' launches would find nothing to do
     HIP_TRY(hipSetDevice(s->device));
     if (s->has_area) {
         int rc = upload_seeds(s, row_seeds, cam->height);
@@ -3219,6 +3225,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
 int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, const uint64_t* seeds, double* out_rgb) {
     if (!s || (n && (!rays || !out_rgb))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;
+    if (!s->spawns) depth = 0;
     HIP_TRY(hipSetDevice(s->device));
     if (s->has_area) {
         int rc = upload_seeds(s, seeds, n);  // a missing list seeds every ray's generator with 0
