@@ -223,7 +223,9 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *                          into equal chunks, a multiple of the stream count
  *   RT_OPT_RECS_PER_PIXEL  ray records reserved per pixel of a chunk (default
  *                          24); a chunk that needs more is split and retried
- *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 4096)
+ *   RT_OPT_GRID_BLOCKS     blocks per kernel launch (default 0 = 4096 with one stream;
+ *                          with more, 1024 for the tracing and 2048 for the shading
+ *                          kernels, so that chunks on different streams share the GPU)
  *   RT_OPT_TRAVERSAL       0: chosen by tree size (default); 1: the 64 lanes of a
  *                          wave walk the tree together; 2: every lane walks on
  *                          its own (large trees; meshes by a hierarchy of their

@@ -2437,7 +2437,7 @@ struct rt_scene {
     Workspace ws[MAX_STREAMS];
     int n_streams = 2;
     int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane, 3: the reference's walk
-    uint32_t grid_blocks = 4096;        // blocks of every level kernel (they stride over the rays)
+    uint32_t grid_blocks = 0;           // blocks of every level kernel (they stride over the rays); 0: see level_grid
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
@@ -2520,6 +2520,17 @@ struct FirstLevel {   // where the first level's rays come from
 bool uses_lane_walk(const rt_scene* s) { return s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS); }
 bool reference_walk(const rt_scene* s) { return s->traversal == 3; }  // no device-only shortcut anywhere
 bool fused_shadows(const rt_scene* s, bool per_lane) { return !s->has_area && !per_lane && !reference_walk(s); }
+// Blocks per level kernel.  A k_trace block is 4 waves of the 16 a CU holds, so 1024 blocks are one
+// full GPU of them.  A chunk rendered alone wants several rounds of blocks (the hardware hands a
+// freed slot to the next block, which evens out walks of different length); with chunks on two or
+// more streams, one round per stream leaves the other stream's kernels room to run beside it.
+uint32_t level_grid(const rt_scene* s, bool trace) {
+    if (s->grid_blocks) return s->grid_blocks;
+    // measured on the 10000x5000 headline frame: 64.8 -> 63.7 ms; lane walks differ too much in length
+    // for a single round of blocks (3000x1200 bounding-box frame: 4.4 -> 4.8 ms)
+    if (s->n_streams > 1 && !uses_lane_walk(s)) return trace ? 1024u : 2048u;
+    return 4096u;
+}
 template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
 void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
     if constexpr (HAS_CSG && !PER_LANE) {
@@ -2541,7 +2552,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
                 uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
     hipStream_t st = w.stream;
     const uint32_t n_levels = depth + 1;
-    const dim3 grid(s->grid_blocks), block(256);
+    const dim3 grid(level_grid(s, false)), grid_trace(level_grid(s, true)), block(256);
     LevelArgs A = base;
     A.levels = w.levels;
     A.n_levels = n_levels;
@@ -2559,9 +2570,9 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         A.level = level;
         A.depth_remaining = depth - level;
         if (first.primary && level == 0)
-            launch_trace<true, HAS_CSG, PER_LANE>(s, grid, st, A);
+            launch_trace<true, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
         else
-            launch_trace<false, HAS_CSG, PER_LANE>(s, grid, st, A);
+            launch_trace<false, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
     }
     tot.trace_launches += n_levels;
     HIP_TRY(hipGetLastError());
@@ -3060,7 +3071,7 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
             s->min_chunks = (uint32_t)value;
             return RT_OK;
         case RT_OPT_GRID_BLOCKS:
-            if (value < 1 || value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 1..65536");
+            if (value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 0..65536 (0: chosen by the number of streams)");
             s->grid_blocks = (uint32_t)value;
             return RT_OK;
     }
