@@ -70,10 +70,10 @@ typedef struct rt_scene_desc {
                                   src/object/csg/mod.rs:18); ignored for leaves.  A
                                   csg's box may be stale (csg/mod.rs:117-121) and only
                                   ever decides what the reference lets it decide; a
-                                  group's box must hold everything below it, as
-                                  Group::bounding_box sees to (group/mod.rs:109-139):
-                                  the walk skips a group it enters beyond the closest
-                                  hit so far                                        */
+                                  group's finite box over bounded shapes must hold
+                                  everything below it, as Group::bounding_box sees to
+                                  (group/mod.rs:109-139): the walk skips such a group
+                                  when it enters it beyond the closest hit so far     */
 
     uint32_t n_leaves;
     const uint32_t *leaf_shape;    /* RT_SPHERE ...                                 */

@@ -130,6 +130,8 @@ struct Ray { V3 o, d; };
 // The tree is one stream of 64-byte units in depth-first order.  A record
 // starts with four dwords:
 //   w0  kind (bits 0-7: RT_SPHERE..RT_TRIANGLE, K_GROUP, K_CSG) | casts_shadow << 8 | closed << 9
+//       | leaf has a bounding sphere in `cull` << 10 | leaf may be skipped when wholly behind the
+//       origin: << 11 in a recording walk, << 16 in a plain one (groups: MESH_BIT .. see below)
 //   w1  group / csg: unit position of the first record after the subtree; leaf: material index
 //   w2  leaf index / csg index
 //   w3  leaf: structural-equality class
@@ -142,7 +144,8 @@ struct Ray { V3 o, d; };
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
 constexpr uint32_t MESH_BIT = 1u << 12;  // group header w0: the subtree is a mesh with a hierarchy of its own (w2 root, w3 matrix)
 constexpr uint32_t MESH_ALL_CAST = 1u << 14, MESH_NONE_CAST = 1u << 15;  // mesh root: every / no triangle casts a shadow
-constexpr uint32_t NESTED_BIT = 1u << 13;  // group inside a mesh: its box lies within the box of every group up to the mesh's root
+constexpr uint32_t NESTED_BIT = 1u << 13;
+constexpr uint32_t GROUP_SOUND = 1u << 17;  // group: finite box over bounded shapes only, so it holds everything below it  // group inside a mesh: its box lies within the box of every group up to the mesh's root
 struct DevScene {
     uint32_t n_units, n_lights, class_words, draws_per_shade;
     uint32_t n_materials, n_patterns;
@@ -565,9 +568,11 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             uint32_t end = w1;
             // Beyond the reference's test: a box entered after the closest hit so far cannot hold a
             // closer one (nor anything that sorts before it), so its subtree is skipped as well.  Only
-            // for groups, whose box always holds their children (object/group/mod.rs:109-115,131-139);
-            // a csg keeps the box it was built with when it is moved (object/csg/mod.rs:117-121).
-            if (CULL && kind == K_GROUP && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
+            // for groups whose box holds their children (object/group/mod.rs:109-115,131-139; GROUP_SOUND
+            // leaves out those with an unbounded shape below them, whose boxes come out of arithmetic
+            // with infinities); a csg keeps the box it was built with when it is moved
+            // (object/csg/mod.rs:117-121).
+            if (CULL && kind == K_GROUP && (w0 & GROUP_SOUND) && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             if (act && !hit) skip_until = end;
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && act && hit) {
@@ -596,7 +601,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
             const bool outside = cc > r2;
             const bool miss = outside && b * b < dd * (cc - r2);
-            const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
+            const bool behind = outside && b < 0.0 && (w0 & (record ? 1u << 11 : 1u << 16));
             // entry parameter >= b/dd - r/|d|: beyond the hit so far iff b - t*dd > r*|d|, squared to avoid |d|
             const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
             const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
@@ -854,7 +859,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             double t0, t1;
             bool hit = box_intersect(ray, u0[2], u0[3], u0[4], u0[5], u0[6], u0[7], t0, t1);
             if (count) flops += F_BOX;
-            if (CULL && kind == K_GROUP && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
+            if (CULL && kind == K_GROUP && (w0 & GROUP_SOUND) && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             uint32_t next = hit ? i + 1 : w1;
             if constexpr (CULL) {
                 bool in_csg = false;
@@ -893,7 +898,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                 const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
                 const bool outside = cc > r2;
                 const bool miss = outside && b * b < dd * (cc - r2);
-                const bool behind = outside && b < 0.0 && ((w0 & (1u << 11)) || !record);
+                const bool behind = outside && b < 0.0 && (w0 & (record ? 1u << 11 : 1u << 16));
                 const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
                 const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
                 culled = miss || behind || beyond;
@@ -2851,9 +2856,15 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 recd[15] = d->leaf_param[(size_t)leaf * 3 + 1];
                 if (bounding_sphere(shape, inv, recd[14], recd[15], &cull[(size_t)unit_of[i] * 6])) {
                     rec[0] |= 1u << 10;
-                    // a sphere or cube outside any csg is always entered and left: wholly behind the
-                    // origin it toggles the container list twice, i.e. not at all
-                    if ((shape == RT_SPHERE || shape == RT_CUBE) && !inside_csg(i)) rec[0] |= 1u << 11;
+                    // Wholly behind the origin a leaf only has intersections with t < 0.  A walk that
+                    // records wants those too, unless they cancel: a sphere or cube outside any csg is
+                    // always entered and left, which toggles the container list twice (bit 11).  A walk
+                    // that only wants the closest hit can skip the leaf (bit 16) - but inside a csg only
+                    // if it is entered and left: an open cylinder or a cone can be crossed once, which
+                    // flips the csg's inside state for everything in front of the origin.
+                    const bool in_csg = inside_csg(i), pairs = shape == RT_SPHERE || shape == RT_CUBE;
+                    if (pairs && !in_csg) rec[0] |= 1u << 11;
+                    if (pairs || !in_csg) rec[0] |= 1u << 16;
                 }
             }
         } else {
@@ -2863,6 +2874,27 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             rec[1] = unit_of[d->node_skip[i]];
             rec[2] = csg ? d->node_arg[i] : 0;
             for (int k = 0; k < 6; k++) recd[2 + k] = d->node_bbox[(size_t)i * 6 + k];
+        }
+    }
+
+    // groups whose stored box certainly holds their subtree: all six coordinates finite and no
+    // unbounded shape below (a rotated endless cylinder's box is made of inf - inf)
+    {
+        std::vector<uint8_t> bounded(d->n_nodes, 1);
+        for (uint32_t i = d->n_nodes; i-- > 0;) {  // children have higher indices than their parent
+            if (d->node_kind[i] == RT_NODE_LEAF) {
+                const uint32_t leaf = d->node_arg[i], shape = d->leaf_shape[leaf];
+                const double mn = d->leaf_param[(size_t)leaf * 3 + 0], mx = d->leaf_param[(size_t)leaf * 3 + 1];
+                if (shape == RT_PLANE) bounded[i] = 0;
+                if ((shape == RT_CYLINDER || shape == RT_CONE) && !(std::isfinite(mn) && std::isfinite(mx))) bounded[i] = 0;
+                const double* inv = d->leaf_inv + (size_t)leaf * 12;
+                for (int k = 0; k < 12; k++) if (!std::isfinite(inv[k])) bounded[i] = 0;
+            } else {
+                for (uint32_t j = i + 1; j < d->node_skip[i]; j = d->node_skip[j]) bounded[i] = bounded[i] && bounded[j];
+                bool finite = true;
+                for (int k = 0; k < 6; k++) finite = finite && std::isfinite(d->node_bbox[(size_t)i * 6 + k]);
+                if (d->node_kind[i] == RT_NODE_GROUP && bounded[i] && finite) stream[(size_t)unit_of[i] * 16] |= GROUP_SOUND;
+            }
         }
     }
 

@@ -1,0 +1,224 @@
+"""Random scenes: every device walk against the reference's walk, and against the CPU oracle.
+
+The scenes are generated as scene-file text (the grammar of src/scene/*.rs: shapes, groups with
+`divide`, csgs nested through `type:`, materials with patterns, `shadow: false`, point and area
+lights), so they also run through the host's loader and the flattening.  What must hold:
+
+* traversal 0 (default), 1 (wave walk) and 2 (lane walk, with the meshes' own hierarchies) give
+  the frame of traversal 3 (the reference's walk, no device-only shortcut) bit for bit, with the
+  same ray counters;
+* every third scene also equals the oracle's frame (8-bit image identical, f64 within 1e-9).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import raytracer_amd as ra
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REL_TOL = 1e-9
+
+
+def emit(value, indent=0):
+    """Block-style text in the shipped scenes' style: mappings and lists of mappings in block form,
+    lists of scalars (and the rows of a transform list) in flow form."""
+    pad = " " * indent
+    out = []
+    for key, v in value.items():
+        if isinstance(v, dict):
+            out.append("%s%s:" % (pad, key))
+            out.append(emit(v, indent + 4))
+        elif isinstance(v, list) and v and isinstance(v[0], dict):
+            out.append("%s%s:" % (pad, key))
+            for item in v:
+                body = emit(item, indent + 6).split("\n")
+                out.append("%s    - %s" % (pad, body[0].lstrip()))
+                out.extend(body[1:])
+        elif isinstance(v, list) and v and isinstance(v[0], list):
+            out.append("%s%s:" % (pad, key))
+            for row in v:
+                out.append("%s    - [%s]" % (pad, ", ".join(scalar(x) for x in row)))
+        elif isinstance(v, list):
+            out.append("%s%s: [%s]" % (pad, key, ", ".join(scalar(x) for x in v)))
+        else:
+            out.append("%s%s: %s" % (pad, key, scalar(v)))
+    return "\n".join(out)
+
+
+def scalar(x):
+    if isinstance(x, bool):
+        return "true" if x else "false"
+    if isinstance(x, float):
+        return repr(round(x, 4))
+    return str(x)
+
+
+def scene_text(items):
+    lines = []
+    for item in items:
+        body = emit(item, 2).split("\n")
+        lines.append("- " + body[0].lstrip())
+        lines.extend(body[1:])
+    return "\n".join(lines) + "\n"
+
+
+class Gen:
+    def __init__(self, seed, style=0):
+        """style 0: a loose arrangement; 1: crowded glass (long container lists, origins inside
+        objects); 2: mostly csgs, nested deeper, with planes among their operands."""
+        self.r = np.random.RandomState(seed)
+        self.style = style
+        self.p_glass = 0.7 if style == 1 else 0.3
+        self.spread = 1.3 if style == 1 else 3.0
+        self.csg_depth = 3 if style == 2 else 2
+
+    def u(self, lo, hi):
+        return float(self.r.uniform(lo, hi))
+
+    def chance(self, p):
+        return bool(self.r.uniform() < p)
+
+    def colour(self):
+        return [self.u(0, 1), self.u(0, 1), self.u(0, 1)]
+
+    def transform(self, spread):
+        ops = []
+        if self.chance(0.7):
+            s = self.u(0.3, 1.2)
+            ops.append(["scale", s, s * self.u(0.6, 1.4), s * self.u(0.6, 1.4)] if self.chance(0.5) else ["scale", s, s, s])
+        if self.chance(0.5):
+            ops.append([["rotate-x", "rotate-y", "rotate-z"][self.r.randint(3)], self.u(-3.1, 3.1)])
+        ops.append(["translate", self.u(-spread, spread), self.u(0, spread), self.u(-spread, spread)])
+        return ops
+
+    def material(self, allow_glass=True):
+        m = {}
+        if self.chance(0.3):
+            kind = ["stripe", "checker", "ring", "gradient"][self.r.randint(4)]
+            m["pattern"] = {"kind": kind, "a": self.colour(), "b": self.colour(),
+                            "transform": [["scale", self.u(0.2, 0.8), self.u(0.2, 0.8), self.u(0.2, 0.8)]]}
+        else:
+            m["color"] = self.colour()
+        if self.chance(0.5):
+            m["specular"] = self.u(0, 1)
+            m["shininess"] = self.u(5, 200)
+        if self.chance(0.35):
+            m["reflective"] = self.u(0.1, 0.9)
+        if allow_glass and self.chance(self.p_glass):
+            m["transparency"] = self.u(0.3, 1.0)
+            m["refractive_index"] = self.u(1.0, 2.0)
+            m["diffuse"] = self.u(0.05, 0.4)
+        return m
+
+    def leaf(self, key, spread):
+        kind = ["sphere", "cube", "cylinder", "cone", "sphere", "cube"][self.r.randint(6)]
+        if self.style == 2 and key == "type" and self.chance(0.1):
+            kind = "plane"
+        o = {key: kind}
+        if kind in ("cylinder", "cone"):
+            if self.chance(0.8):
+                lo = self.u(-1.5, 0.0)
+                o["min"] = lo
+                o["max"] = lo + self.u(0.5, 2.0)
+                o["closed"] = self.chance(0.6)
+        o["material"] = self.material()
+        o["transform"] = self.transform(spread)
+        if self.chance(0.15):
+            o["shadow"] = False
+        return o
+
+    def csg(self, key, spread, depth):
+        def side():
+            roll = self.r.uniform()
+            if depth < self.csg_depth and roll < 0.25:
+                return self.csg("type", spread, depth + 1)
+            if depth < 2 and roll < 0.4:
+                return self.group("type", spread * 0.7, depth + 1, in_csg=True)
+            return self.leaf("type", spread)
+        # the two sides overlap more often than not
+        left, right = side(), side()
+        if "transform" in left and "transform" in right and self.chance(0.7):
+            t = left["transform"][-1]
+            right["transform"][-1] = ["translate", t[1] + self.u(-0.6, 0.6), t[2] + self.u(-0.6, 0.6), t[3] + self.u(-0.6, 0.6)]
+        return {key: "csg", "operation": ["union", "intersection", "difference"][self.r.randint(3)], "left": left, "right": right}
+
+    def group(self, key, spread, depth, in_csg=False):
+        n = self.r.randint(1, 5)
+        children = []
+        for _ in range(n):
+            roll = self.r.uniform()
+            if depth < 2 and roll < 0.2:
+                children.append(self.group("add", spread * 0.7, depth + 1, in_csg))
+            elif depth < 2 and roll < 0.35 and not in_csg:
+                children.append(self.csg("add", spread * 0.7, depth + 1))
+            else:
+                children.append(self.leaf("add", spread))
+        g = {key: "group", "children": children}
+        if self.chance(0.6):
+            g["transform"] = self.transform(spread)
+        if self.chance(0.3):
+            g["divide"] = int(self.r.randint(1, 4))
+        return g
+
+    def scene(self, with_mesh, with_area):
+        items = [{"add": "camera", "width": 160, "height": 100, "field-of-view": 1.0,
+                  "from": [self.u(-1, 1), self.u(1.5, 3), -7.0], "to": [0.0, 1.0, 0.0], "up": [0.0, 1.0, 0.0]}]
+        if self.chance(0.8):
+            floor = {"add": "plane", "material": self.material(allow_glass=False)}
+            items.append(floor)
+        p_group, p_csg = (0.15, 0.85) if self.style == 2 else (0.3, 0.55)
+        for _ in range(self.r.randint(2, 6)):
+            roll = self.r.uniform()
+            if roll < p_group:
+                items.append(self.group("add", self.spread, 0))
+            elif roll < p_csg:
+                items.append(self.csg("add", self.spread, 0))
+            else:
+                items.append(self.leaf("add", self.spread))
+        if with_mesh:
+            items.append({"add": "obj", "file": "obj/teapot.obj", "divide": int(self.r.randint(5, 60)),
+                          "material": self.material(),
+                          "transform": [["scale", 0.08, 0.08, 0.08], ["rotate-x", -1.5708],
+                                        ["translate", self.u(-2, 2), 0.0, self.u(-1, 2)]]})
+        for _ in range(self.r.randint(1, 3)):
+            items.append({"add": "light", "at": [self.u(-8, 8), self.u(4, 10), self.u(-10, -2)],
+                          "intensity": [self.u(0.3, 1.0)] * 3})
+        if with_area:
+            items.append({"add": "light", "corner": [self.u(-2, 2), 6.0, -4.0], "uvec": [1.5, 0.0, 0.0], "usteps": 2,
+                          "vvec": [0.0, 0.0, 1.5], "vsteps": 2, "intensity": [0.5, 0.5, 0.5]})
+        return scene_text(items)
+
+
+def render(text, mode, seed):
+    g = ra.Scene.from_text(text, 1.0, seed, ROOT)
+    seeds = g.row_seeds()
+    g.set_option(ra.OPT_TRAVERSAL, mode)
+    return g.render(4, seeds)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_scene_every_walk_equals_the_reference_walk(seed):
+    gen = Gen(1000 + seed, style=(seed // 12) % 3)
+    text = gen.scene(with_mesh=seed % 3 == 0, with_area=seed % 6 == 5)
+    try:
+        ref, sref = render(text, 3, seed)
+    except ra.RtError as e:
+        # a per-ray list bound of this build (nested csgs can pass it) or a NaN distance: the other
+        # walks must not return an image either unless they never build the offending list
+        assert e.code in (ra.RT_ERR_CAPACITY, ra.RT_ERR_NAN), text
+        pytest.skip("reference walk: %s" % e)
+    for mode in (0, 1, 2):
+        got, st = render(text, mode, seed)
+        same = np.array_equal(got.pixels.view(np.uint64), ref.pixels.view(np.uint64))
+        assert same, "traversal %d differs in %d pixels\n%s" % (mode, int((got.pixels != ref.pixels).any(axis=2).sum()), text)
+        for key in ("secondary_rays", "shadow_rays", "shade_hits"):
+            assert st[key] == sref[key], (mode, key)
+    if seed % 12 < 4:
+        o = ol.OracleScene.from_text(text, 1.0, seed, ROOT)
+        want = o.render_rows(4, o.row_seeds(), threads=16)
+        assert int((ref.rgb8 != ol.to_u8(want)).any(axis=2).sum()) == 0, text
+        rel = np.abs(ref.pixels - want) / np.maximum(np.abs(want), 1e-12)
+        assert float(rel.max()) <= REL_TOL, text
