@@ -68,10 +68,11 @@ def scene_text(items):
 class Gen:
     def __init__(self, seed, style=0):
         """style 0: a loose arrangement; 1: crowded glass (long container lists, origins inside
-        objects); 2: mostly csgs, nested deeper, with planes among their operands."""
+        objects); 2: mostly csgs, nested deeper, with planes among their operands; 3: meshes - glass
+        ones, ones that cast no shadow, in groups beside other shapes, as csg operands."""
         self.r = np.random.RandomState(seed)
         self.style = style
-        self.p_glass = 0.7 if style == 1 else 0.3
+        self.p_glass = 0.7 if style == 1 else 0.5 if style == 3 else 0.3
         self.spread = 1.3 if style == 1 else 3.0
         self.csg_depth = 3 if style == 2 else 2
 
@@ -163,6 +164,16 @@ class Gen:
             g["divide"] = int(self.r.randint(1, 4))
         return g
 
+    def mesh(self, key):
+        o = {key: "obj", "file": "obj/teapot.obj", "material": self.material(),
+             "transform": [["scale", 0.08, 0.08, 0.08], ["rotate-x", -1.5708], ["rotate-y", self.u(-3, 3)],
+                           ["translate", self.u(-2.5, 2.5), self.u(0, 1), self.u(-1, 2.5)]]}
+        if self.chance(0.7):
+            o["divide"] = int(self.r.randint(2, 80))
+        if self.chance(0.25):
+            o["shadow"] = False
+        return o
+
     def scene(self, with_mesh, with_area):
         items = [{"add": "camera", "width": 160, "height": 100, "field-of-view": 1.0,
                   "from": [self.u(-1, 1), self.u(1.5, 3), -7.0], "to": [0.0, 1.0, 0.0], "up": [0.0, 1.0, 0.0]}]
@@ -178,7 +189,18 @@ class Gen:
                 items.append(self.csg("add", self.spread, 0))
             else:
                 items.append(self.leaf("add", self.spread))
-        if with_mesh:
+        if self.style == 3:
+            for _ in range(self.r.randint(1, 3)):
+                roll = self.r.uniform()
+                if roll < 0.5:
+                    items.append(self.mesh("add"))
+                elif roll < 0.8:
+                    items.append({"add": "group", "children": [self.mesh("add"), self.leaf("add", 2.0)],
+                                  "transform": self.transform(1.0)})
+                else:
+                    items.append({"add": "csg", "operation": ["union", "intersection", "difference"][self.r.randint(3)],
+                                  "left": self.mesh("type"), "right": self.leaf("type", 2.0)})
+        elif with_mesh:
             items.append({"add": "obj", "file": "obj/teapot.obj", "divide": int(self.r.randint(5, 60)),
                           "material": self.material(),
                           "transform": [["scale", 0.08, 0.08, 0.08], ["rotate-x", -1.5708],
@@ -201,7 +223,7 @@ def render(text, mode, seed):
 
 @pytest.mark.parametrize("seed", range(240))
 def test_random_scene_every_walk_equals_the_reference_walk(seed):
-    gen = Gen(1000 + seed, style=(seed // 12) % 3)
+    gen = Gen(1000 + seed, style=(seed // 12) % 4)
     text = gen.scene(with_mesh=seed % 3 == 0, with_area=seed % 6 == 5)
     try:
         ref, sref = render(text, 3, seed)
