@@ -175,8 +175,11 @@ class Gen:
         return o
 
     def scene(self, with_mesh, with_area):
-        items = [{"add": "camera", "width": 160, "height": 100, "field-of-view": 1.0,
-                  "from": [self.u(-1, 1), self.u(1.5, 3), -7.0], "to": [0.0, 1.0, 0.0], "up": [0.0, 1.0, 0.0]}]
+        eye = [self.u(-1, 1), self.u(1.5, 3), -7.0]
+        if self.style == 1 and self.chance(0.5):  # among (often inside) the glass objects
+            eye = [self.u(-1, 1), self.u(0.2, 1.5), self.u(-1.5, 0.5)]
+        items = [{"add": "camera", "width": 160, "height": 100, "field-of-view": 1.0 if eye[2] < -6 else 1.6,
+                  "from": eye, "to": [0.0, 1.0, 1.0 if eye[2] > -6 else 0.0], "up": [0.0, 1.0, 0.0]}]
         if self.chance(0.8):
             floor = {"add": "plane", "material": self.material(allow_glass=False)}
             items.append(floor)
