@@ -247,3 +247,47 @@ def test_random_scene_every_walk_equals_the_reference_walk(seed):
         assert int((ref.rgb8 != ol.to_u8(want)).any(axis=2).sum()) == 0, text
         rel = np.abs(ref.pixels - want) / np.maximum(np.abs(want), 1e-12)
         assert float(rel.max()) <= REL_TOL, text
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_options_partitions_and_single_rays(seed):
+    """The same random scenes through the other entry points and settings: tiny chunks with a record
+    budget that forces splits, a frame put together from the rows of three ranks, and
+    World::colour_at for single rays (world.rs:33-49) against the oracle."""
+    gen = Gen(5000 + seed, style=seed % 4)
+    text = gen.scene(with_mesh=seed % 3 == 0, with_area=seed % 2 == 1)
+    g = ra.Scene.from_text(text, 1.0, seed, ROOT)
+    seeds = g.row_seeds()
+    try:
+        base, _ = g.render(4, seeds)
+    except ra.RtError as e:
+        assert e.code in (ra.RT_ERR_CAPACITY, ra.RT_ERR_NAN), text
+        pytest.skip(str(e))
+    h = ra.Scene.from_text(text, 1.0, seed, ROOT)
+    h.row_seeds()
+    for k, v in {ra.OPT_STREAMS: 1 + seed % 3, ra.OPT_CHUNK_PIXELS: 8 * g.width, ra.OPT_RECS_PER_PIXEL: 1,
+                 ra.OPT_GRID_BLOCKS: 5 + seed}.items():
+        h.set_option(k, v)
+    got, _ = h.render(4, seeds)
+    assert np.array_equal(got.pixels.view(np.uint64), base.pixels.view(np.uint64)), text
+    frame = np.zeros_like(base.pixels)
+    for rank in range(3):
+        part = ra.Partition(8, rank, 3)
+        c, _ = g.render(4, seeds, part)
+        frame[ra.local_rows(g.height, part)] = c.pixels
+    assert np.array_equal(frame.view(np.uint64), base.pixels.view(np.uint64)), text
+    # single rays from points around the scene towards its middle
+    r = np.random.RandomState(seed)
+    n = 257
+    origin = r.uniform(-6, 6, size=(n, 3))
+    origin[:, 1] = np.abs(origin[:, 1]) + 0.1
+    target = r.uniform(-2, 2, size=(n, 3))
+    direction = target - origin
+    direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+    rays = np.hstack([origin, direction])
+    ray_seeds = r.randint(0, 2**62, size=n).astype(np.uint64)
+    o = ol.OracleScene.from_text(text, 1.0, seed, ROOT)
+    want = o.colour_at(rays, 4, ray_seeds)
+    have = g.colour_at(rays, 4, ray_seeds)
+    rel = np.abs(have - want) / np.maximum(np.abs(want), 1e-12)
+    assert float(rel.max()) <= REL_TOL, text
