@@ -227,8 +227,8 @@ class Gen:
             items.append({"add": "light", "at": [self.u(-8, 8), self.u(4, 10), self.u(-10, -2)],
                           "intensity": [self.u(0.3, 1.0)] * 3})
         if with_area:
-            items.append({"add": "light", "corner": [self.u(-2, 2), 6.0, -4.0], "uvec": [1.5, 0.0, 0.0], "usteps": 2,
-                          "vvec": [0.0, 0.0, 1.5], "vsteps": 2, "intensity": [0.5, 0.5, 0.5]})
+            items.append({"add": "light", "corner": [self.u(-2, 2), 6.0, -4.0], "uvec": [1.5, 0.0, 0.0], "usteps": int(self.r.randint(1, 5)),
+                          "vvec": [0.0, 0.0, 1.5], "vsteps": int(self.r.randint(1, 5)), "intensity": [0.5, 0.5, 0.5]})
         return scene_text(items)
 
 
