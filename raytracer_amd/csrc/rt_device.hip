@@ -1395,9 +1395,10 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
-                     Work& flops, uint32_t& err, uint32_t& n_shadow) {
+                     Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE) {
     if (__ballot(on) == 0ull) return;
-    for (uint32_t l = 0; l < S.n_lights; l++) {
+    l_end = min(l_end, S.n_lights);  // a wave-uniform range of lights (all of them unless told otherwise)
+    for (uint32_t l = l_begin; l < l_end; l++) {
         const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
         const uint32_t samples = usteps * vsteps;
         const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
@@ -1692,8 +1693,15 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
     const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
     Work flops{};
     uint32_t err = 0, n_shadow = 0;
-    for (uint32_t first = blockIdx.x * 256; first < total; first += gridDim.x * 256) {
+    // Without an area light a shade point's lights are independent (no rng stream runs through
+    // them): a lane-walked tree takes one (block of records, light) pair per step, which shortens
+    // each lane's chain of walks and multiplies the number of waves in flight.
+    const bool per_light = PER_LANE && !A.rng_states && S.n_lights > 1;
+    const unsigned long long n_blocks = (total + 255u) / 256u, n_steps = n_blocks * (per_light ? S.n_lights : 1u);
+    for (unsigned long long step = blockIdx.x; step < n_steps; step += gridDim.x) {
         LOOP_FENCE();
+        const uint32_t light = per_light ? (uint32_t)(step / n_blocks) : 0u;
+        const uint32_t first = (uint32_t)(step % n_blocks) * 256u;
         const uint32_t idx = first + threadIdx.x;
         bool on = idx < total;
         const uint32_t rec_idx = on ? idx : 0;
@@ -1704,7 +1712,8 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
         const V3 normal = mk(A.R.nx[rec_idx], A.R.ny[rec_idx], A.R.nz[rec_idx]);
-        intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
+        if (per_light) intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
+        else intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     uint32_t s_shadow = wave_sum_u32(n_shadow);
     uint32_t s_flops_lo = wave_sum_u32(flops.flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops.flops >> 16);
