@@ -144,7 +144,8 @@ def test_tuning_options_do_not_change_the_image(scene, depth):
 def test_full_size_headline_frame_properties():
     """chapter11 at 10000x5000, depth 30: far too large for the oracle as a whole, so check
     (a) 24 evenly spaced rows against the oracle, 8-bit exact and within the colour tolerance,
-    (b) the 2-rank row split reproduces the single-rank frame bit for bit (on a 10000x400 band)."""
+    (b) the 2-rank row split reproduces the single-rank frame bit for bit,
+    (c) the reference's walk (traversal 3) gives the same 50 M pixels, f64 for f64."""
     g, o = pair("scenes/chapter11.yaml", 10.0)
     seeds = g.row_seeds()
     canvas, st = g.render(30, seeds, want_f64=True)
@@ -161,6 +162,12 @@ def test_full_size_headline_frame_properties():
         part_frames.append((ra.local_rows(g.height, part), c.rgb8))
     for rows_r, img in part_frames:
         assert np.array_equal(img, canvas.rgb8[rows_r])
+    # (c) the whole frame again with the reference's walk (no device-only shortcut): every f64 equal
+    g.set_option(ra.OPT_TRAVERSAL, 3)
+    plain, st3 = g.render(30, seeds, want_f64=True)
+    assert np.array_equal(plain.pixels.view(np.uint64), canvas.pixels.view(np.uint64))
+    for key in ("secondary_rays", "shadow_rays", "shade_hits"):
+        assert st3[key] == st[key], key
 
 
 def test_error_paths():
