@@ -239,9 +239,14 @@ def render(text, mode, seed):
     return g.render(4, seeds)
 
 
-@pytest.mark.parametrize("seed", range(240))
+# A longer campaign: RT_FUZZ_COUNT=3000 RT_FUZZ_BASE=50000 python -m pytest tests/test_gpu_fuzz.py -m gpu
+FUZZ_COUNT = int(os.environ.get("RT_FUZZ_COUNT", "240"))
+FUZZ_BASE = int(os.environ.get("RT_FUZZ_BASE", "1000"))
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_COUNT))
 def test_random_scene_every_walk_equals_the_reference_walk(seed):
-    gen = Gen(1000 + seed, style=(seed // 12) % 4)
+    gen = Gen(FUZZ_BASE + seed, style=(seed // 12) % 4)
     text = gen.scene(with_mesh=seed % 3 == 0, with_area=seed % 6 == 5)
     try:
         ref, sref = render(text, 3, seed)
