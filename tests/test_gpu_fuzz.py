@@ -193,7 +193,9 @@ class Gen:
         eye = [self.u(-1, 1), self.u(1.5, 3), -7.0]
         if self.style == 1 and self.chance(0.5):  # among (often inside) the glass objects
             eye = [self.u(-1, 1), self.u(0.2, 1.5), self.u(-1.5, 0.5)]
-        items = [{"add": "camera", "width": 160, "height": 100, "field-of-view": 1.0 if eye[2] < -6 else 1.6,
+        # frames whose sides are no multiples of the 8x8 pixel tiles, taller than wide now and then
+        width, height = int(self.r.randint(40, 200)), int(self.r.randint(30, 130))
+        items = [{"add": "camera", "width": width, "height": height, "field-of-view": 1.0 if eye[2] < -6 else 1.6,
                   "from": eye, "to": [0.0, 1.0, 1.0 if eye[2] > -6 else 0.0], "up": [0.0, 1.0, 0.0]}]
         if self.chance(0.8):
             floor = {"add": "plane", "material": self.material(allow_glass=False)}
@@ -232,11 +234,11 @@ class Gen:
         return scene_text(items)
 
 
-def render(text, mode, seed):
+def render(text, mode, seed, depth=4):
     g = ra.Scene.from_text(text, 1.0, seed, ROOT)
     seeds = g.row_seeds()
     g.set_option(ra.OPT_TRAVERSAL, mode)
-    return g.render(4, seeds)
+    return g.render(depth, seeds)
 
 
 # A longer campaign: RT_FUZZ_COUNT=3000 RT_FUZZ_BASE=50000 python -m pytest tests/test_gpu_fuzz.py -m gpu
@@ -249,21 +251,22 @@ def test_random_scene_every_walk_equals_the_reference_walk(seed):
     gen = Gen(FUZZ_BASE + seed, style=(seed // 12) % 4)
     text = gen.scene(with_mesh=seed % 3 == 0, with_area=seed % 6 == 5)
     try:
-        ref, sref = render(text, 3, seed)
+        depth = seed % 9  # 0 .. 8 levels of recursion
+        ref, sref = render(text, 3, seed, depth)
     except ra.RtError as e:
         # a per-ray list bound of this build (nested csgs can pass it) or a NaN distance: the other
         # walks must not return an image either unless they never build the offending list
         assert e.code in (ra.RT_ERR_CAPACITY, ra.RT_ERR_NAN), text
         pytest.skip("reference walk: %s" % e)
     for mode in (0, 1, 2):
-        got, st = render(text, mode, seed)
+        got, st = render(text, mode, seed, depth)
         same = np.array_equal(got.pixels.view(np.uint64), ref.pixels.view(np.uint64))
         assert same, "traversal %d differs in %d pixels\n%s" % (mode, int((got.pixels != ref.pixels).any(axis=2).sum()), text)
         for key in ("secondary_rays", "shadow_rays", "shade_hits"):
             assert st[key] == sref[key], (mode, key)
     if seed % 12 < 6:
         o = ol.OracleScene.from_text(text, 1.0, seed, ROOT)
-        want = o.render_rows(4, o.row_seeds(), threads=16)
+        want = o.render_rows(depth, o.row_seeds(), threads=16)
         assert int((ref.rgb8 != ol.to_u8(want)).any(axis=2).sum()) == 0, text
         rel = np.abs(ref.pixels - want) / np.maximum(np.abs(want), 1e-12)
         assert float(rel.max()) <= REL_TOL, text
