@@ -2015,46 +2015,65 @@ __global__ __launch_bounds__(256) void k_order_assign(Recs R, uint32_t base, uin
 }
 // (4) the generator state at every shade point.  Shade point k of a row starts k * draws steps
 // after the row's seed, and the state transition of xoshiro256 is linear over GF(2) (the ++ only
-// scrambles the output), so that state is T^(draws * k) applied to the seeded state: a product of
-// the precomputed matrices jump[b] = T^(draws * 2^b) over the set bits b of k.  A matrix is stored
-// by columns, 4 words each; applying it XORs the columns selected by the state's bits.  One block
-// per row; stepping the generator along the row instead takes one lane 15 ms for 320 000 steps.
+// scrambles the output), so that state is T^(draws * k) applied to the seeded state, with
+// precomputed matrices jump[b] = T^(draws * 2^b).  A matrix is stored by columns, 4 words each;
+// applying it XORs the columns selected by the state's bits.  A few blocks per row (stepping the
+// generator along the row instead takes one lane 15 ms for 320 000 steps).  A wave works on 64
+// consecutive shade points with one state that all its lanes share: every lane XORs the four
+// columns of "its" state bits and a butterfly over the wave folds the 64 partial sums.  It jumps to
+// the first point by the set bits of its index, then walks on by jump[0] (kept in LDS), leaving
+// the state with the lane of the same number.
 constexpr uint32_t RNG_JUMPS = 26;  // shade points per row < 2^26
+DEV void rng_apply(const unsigned long long* m, unsigned long long* u, uint32_t lane) {
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+    for (int wd = 0; wd < 4; wd++) {
+        const unsigned long long mask = 0ull - ((u[wd] >> lane) & 1ull);
+        const unsigned long long* c = m + (size_t)(wd * 64 + lane) * 4;
+        p0 ^= c[0] & mask; p1 ^= c[1] & mask; p2 ^= c[2] & mask; p3 ^= c[3] & mask;
+    }
+    unsigned long long p[4] = {p0, p1, p2, p3};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int lo = __shfl_xor((int)(uint32_t)p[j], off, WAVE), hi = __shfl_xor((int)(uint32_t)(p[j] >> 32), off, WAVE);
+            p[j] ^= ((unsigned long long)(uint32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) u[j] = p[j];
+}
 __global__ __launch_bounds__(256) void k_rng_rows(Rng* states, const uint32_t* row_base, const uint32_t* row_total,
                                                   const unsigned long long* seeds, uint32_t rows, uint32_t chunk_row0,
                                                   uint32_t part_block, uint32_t part_rank, uint32_t part_world,
                                                   const unsigned long long* jump) {
     const uint32_t row = blockIdx.x;
     if (row >= rows) return;
+    __shared__ unsigned long long s_step[1024];  // jump[0]: from one shade point to the next
+    for (uint32_t k = threadIdx.x; k < 1024; k += blockDim.x) s_step[k] = jump[k];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t local = chunk_row0 + row, gy = local;
     if (part_world > 1) gy = ((local / part_block) * part_world + part_rank) * part_block + local % part_block;
     const Rng seeded = rng_seed(seeds[gy]);
     const uint32_t n = row_total[row];
     Rng* out = states + row_base[row];
-    for (uint32_t k0 = 0; k0 < n; k0 += blockDim.x) {
-        const uint32_t k = k0 + threadIdx.x;
-        unsigned long long v[4] = {seeded.s0, seeded.s1, seeded.s2, seeded.s3};
-        for (uint32_t b = 0; b < RNG_JUMPS; b++) {
-            const bool mine = k < n && ((k >> b) & 1u);
-            if (__ballot(mine) == 0ull) continue;
-            const unsigned long long* col = jump + (size_t)b * 1024;
-            unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-            for (int wd = 0; wd < 4; wd++) {
-#pragma unroll 16
-                for (int bit = 0; bit < 64; bit++) {  // unrolled: the column loads are scalar and should overlap
-                    const unsigned long long m = 0ull - ((v[wd] >> bit) & 1ull);
-                    // wave-uniform address: through the constant address space these are scalar loads
-                    const CADDR unsigned long long* c = (const CADDR unsigned long long*)(uintptr_t)(col + (size_t)(wd * 64 + bit) * 4);
-                    a0 ^= c[0] & m; a1 ^= c[1] & m; a2 ^= c[2] & m; a3 ^= c[3] & m;
-                }
-            }
-            if (mine) { v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
+    // the row's groups of 64 points are dealt over the blocks of the row (gridDim.y) and their waves
+    for (uint32_t kw = (blockIdx.y * (blockDim.x / 64) + wave) * 64; kw < n; kw += gridDim.y * blockDim.x) {
+        unsigned long long u[4] = {seeded.s0, seeded.s1, seeded.s2, seeded.s3};
+        for (uint32_t b = 6; b < RNG_JUMPS; b++)
+            if ((kw >> b) & 1u) rng_apply(jump + (size_t)b * 1024, u, lane);
+        unsigned long long mine[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < 64; i++) {
+            if (lane == i) { mine[0] = u[0]; mine[1] = u[1]; mine[2] = u[2]; mine[3] = u[3]; }
+            if (kw + i + 1 >= n) break;
+            rng_apply(s_step, u, lane);
         }
-        if (k < n) {
+        if (kw + lane < n) {
             Rng r;
-            r.s0 = v[0]; r.s1 = v[1]; r.s2 = v[2]; r.s3 = v[3];
-            out[k] = r;
+            r.s0 = mine[0]; r.s1 = mine[1]; r.s2 = mine[2]; r.s3 = mine[3];
+            out[kw + lane] = r;
         }
     }
 }
@@ -2630,7 +2649,10 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
                 if (lv[level].n)
                     hipLaunchKernelGGL(k_order_assign, dim3((lv[level].n + 255) / 256), block, 0, st, w.R, lv[level].base,
                                        lv[level].n, width, w.pixel_base, w.row_base, level == 0 ? 1 : 0);
-            hipLaunchKernelGGL(k_rng_rows, dim3(rows), dim3(256), 0, st, w.rng_states, w.row_base, w.row_total,
+            uint32_t most = 0;
+            for (uint32_t r = 0; r < rows; r++) most = std::max(most, totals[r]);
+            const uint32_t blocks_per_row = std::min<uint32_t>(std::max<uint32_t>((most + 255) / 256, 1), 65535);
+            hipLaunchKernelGGL(k_rng_rows, dim3(rows, blocks_per_row), dim3(256), 0, st, w.rng_states, w.row_base, w.row_total,
                                first.seeds, rows, first.primary ? base.chunk_row0 : 0u,
                                first.primary ? base.part_block : 0u, first.primary ? base.part_rank : 0u,
                                first.primary ? base.part_world : 1u, s->rng_jump);
