@@ -18,6 +18,7 @@ import oracle_lib as ol
 import raytracer_amd as ra
 
 pytestmark = pytest.mark.gpu
+FUZZ_OBJ = os.environ.get("RT_FUZZ_OBJ", "obj/teapot.obj")  # the mesh the scenes use (obj/dragon.obj: 23 490 triangles)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REL_TOL = 1e-9
 
@@ -180,7 +181,7 @@ class Gen:
         return g
 
     def mesh(self, key):
-        o = {key: "obj", "file": "obj/teapot.obj", "material": self.material(),
+        o = {key: "obj", "file": FUZZ_OBJ, "material": self.material(),
              "transform": [["scale", 0.08, 0.08, 0.08], ["rotate-x", -1.5708], ["rotate-y", self.u(-3, 3)],
                            ["translate", self.u(-2.5, 2.5), self.u(0, 1), self.u(-1, 2.5)]]}
         if self.chance(0.7):
@@ -221,7 +222,7 @@ class Gen:
                     items.append({"add": "csg", "operation": ["union", "intersection", "difference"][self.r.randint(3)],
                                   "left": self.mesh("type"), "right": self.leaf("type", 2.0)})
         elif with_mesh:
-            items.append({"add": "obj", "file": "obj/teapot.obj", "divide": int(self.r.randint(5, 60)),
+            items.append({"add": "obj", "file": FUZZ_OBJ, "divide": int(self.r.randint(5, 60)),
                           "material": self.material(),
                           "transform": [["scale", 0.08, 0.08, 0.08], ["rotate-x", -1.5708],
                                         ["translate", self.u(-2, 2), 0.0, self.u(-1, 2)]]})
