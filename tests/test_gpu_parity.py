@@ -37,6 +37,9 @@ CASES = [
     ("scenes/chapter11-water.yaml", 0.5, 5), ("scenes/chapter12.yaml", 0.3, 5), ("scenes/chapter13.yaml", 0.4, 5),
     ("scenes/chapter14.yaml", 0.4, 5), (None, 0.5, 20), ("scenes/chapter15.yaml", 0.2, 5),
     ("scenes/chapter15-dragon.yaml", 0.15, 5), ("scenes/chapter16.yaml", 0.4, 5), ("scenes/bounding-box.yaml", 0.2, 5),
+    # the 10x10 jittered area light: 400 rng draws per shade point in the reference's per-row order
+    # (light/area.rs:48-91, material.rs:57-64, camera.rs:143-161); f64 must come out bit for bit
+    ("scenes/area-light.yaml", 0.5, 5), ("scenes/area-light.yaml", 1.0, 5),
 ]
 
 
@@ -50,14 +53,19 @@ def test_frame_matches_oracle(scene, scale, depth):
     bad8, rel = compare(canvas, ref)
     assert bad8 == 0, f"{bad8} differing 8-bit pixels"
     assert rel <= REL_TOL, rel
+    if scene == "scenes/area-light.yaml":
+        # ray paths do not depend on the rng and every draw is taken in the reference's order, so the
+        # only differences left are those of device pow() against glibc's
+        assert rel <= 1e-13, rel
     c = o.counters()
     assert st["primary_rays"] == g.width * g.height
     assert (st["secondary_rays"], st["shadow_rays"], st["shade_hits"]) == (c["secondary"], c["shadow"], c["shade"])
 
 
-@pytest.mark.parametrize("name", ["chapter6", "chapter11", "chapter13", "chapter14-spheres", "chapter16"])
+@pytest.mark.parametrize("name", sorted(GOLDEN))
 def test_frame_matches_reference_render(name):
-    """Rows of the reference's own images at --scale 3 (tests/golden), 8-bit exact."""
+    """Rows of the reference's own images at --scale 3 (tests/golden), 8-bit exact; bounding-box
+    within its counted z-fighting band (golden_scenes.py)."""
     cfg = GOLDEN[name]
     g = ra.Scene.generate_random_spheres(SCALE, SEED) if cfg["scene"] is None else ra.Scene.from_file(os.path.join(ROOT, cfg["scene"]), SCALE, SEED)
     if cfg.get("half_view_ulps"):
@@ -65,7 +73,7 @@ def test_frame_matches_reference_render(name):
     gold = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     canvas, _ = g.render(cfg["depth"], g.row_seeds(), want_f64=False)
     assert (canvas.width, canvas.height) == (int(gold["width"]), int(gold["height"]))
-    assert int((canvas.rgb8[gold["rows"]] != gold["rgb8"]).any(axis=2).sum()) == 0
+    assert int((canvas.rgb8[gold["rows"]] != gold["rgb8"]).any(axis=2).sum()) <= cfg.get("max_mismatch", 0)
 
 
 def test_row_partition_renders_the_same_pixels():
