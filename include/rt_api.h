@@ -202,6 +202,27 @@ int rt_colour_at(rt_scene *scene, uint32_t n, const double *rays, uint32_t depth
                  const uint64_t *seeds, double *out_rgb);
 
 /*
+ * rt_colour_at for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  Same kernels and bit-identical colours as rt_colour_at, but
+ * every device buffer the kernels need (ray records, level table, counters,
+ * statistics) is carved out of one static 64 MiB __device__ array that each GPU
+ * holds from the time the library is loaded; the call makes no hipMalloc /
+ * hipFree and creates no stream or event (it launches on the null stream and
+ * returns when the colours are written).
+ *   rays_dev     n*6 f64 (origin, direction), DEVICE memory
+ *   out_rgb_dev  n*3 f64, DEVICE memory
+ * Limits: n <= rt_noalloc_max_rays() (65536), depth <= 1022, no area light
+ * (RT_ERR_UNSUPPORTED), and the rays together may not spawn more ray records
+ * than the array holds (about 64 MiB / (144 + 8 * lights) bytes):
+ * RT_ERR_CAPACITY with a message that says so.  All calls on one GPU share the
+ * array: calls that overlap on one GPU race, whatever scene they use.
+ */
+int rt_colour_at_noalloc(rt_scene *scene, uint32_t n, const double *rays_dev, uint32_t depth,
+                         double *out_rgb_dev);
+uint32_t rt_noalloc_max_rays(void);
+
+/*
  * Intersection::prepare_computations for the hit of each ray
  * (src/intersection/mod.rs:45-109, src/world.rs:90-126).  Per ray 32 f64:
  *  [0] hit leaf index or -1, [1] t, [2..4] point, [5..7] over_point,

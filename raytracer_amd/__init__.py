@@ -30,6 +30,7 @@ RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY, RT_ERR_NAN = -1
 ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
+    "rt_colour_at_noalloc", "rt_noalloc_max_rays",
 )
 OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS = 1, 2, 3, 4, 5, 6
 HOST_ABI_SYMBOLS = (
@@ -107,6 +108,8 @@ def hip_lib():
         L.rt_colour_at.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.rt_colour_at_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.rt_noalloc_max_rays.restype = C.c_uint32
         _hip = L
     return _hip
 

@@ -43,6 +43,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2178,6 +2179,33 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     if (err) atomicOr(&counters->error, err);
 }
 
+// ---------------------------------------------------------------- static scratch (rt_colour_at_noalloc)
+// Device memory for callers that must not allocate: the record arrays, level table, counters and
+// statistics lines of one small batch of rays are carved out of this array instead of a Workspace's
+// hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy, at its own address, until
+// the process ends; the name is only a host-side handle, the address comes from hipGetSymbolAddress.
+}  // namespace
+constexpr size_t SCRATCH_BYTES = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+namespace {
+constexpr int SCRATCH_MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[SCRATCH_MAX_DEVICES] = {};  // per device: where that GPU's copy of `scratch` lives
+
+// rays given as n * 6 f64 (origin, direction) into the record columns the first level reads
+__global__ __launch_bounds__(256) void k_load_rays(const double* rays, uint32_t n, Recs R) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + (size_t)i * 6;
+    R.ox[i] = r[0]; R.oy[i] = r[1]; R.oz[i] = r[2];
+    R.dx[i] = r[3]; R.dy[i] = r[4]; R.dz[i] = r[5];
+}
+// a fill kernel instead of hipMemsetAsync: safe to record into a caller's graph
+__global__ __launch_bounds__(256) void k_zero_words(unsigned long long* p, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0ull;
+}
+
 // ---------------------------------------------------------------- host side of the ABI
 thread_local std::string g_error;
 int fail(int code, const std::string& msg) { g_error = msg; return code; }
@@ -2188,6 +2216,22 @@ int fail(int code, const std::string& msg) { g_error = msg; return code; }
         if (e_ != hipSuccess)                                                                 \
             return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
     } while (0)
+
+// Address of the current device's copy of `scratch`, looked up once per device with that device current.
+int scratch_of_current_device(unsigned char** out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return fail(RT_ERR_INVALID, "device ordinal beyond the static scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned no address for the static scratch");
+        g_scratch_ptr[dev] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return RT_OK;
+}
 
 // World-space bounding sphere {centre, radius, radius^2} of a bounded leaf, from rows 0-2 of its
 // inverse transformation; false for unbounded shapes (plane, untruncated cylinder / cone) and
@@ -2457,6 +2501,7 @@ struct Workspace {
     size_t row_cap = 0, row_base_cap = 0;
 };
 constexpr int MAX_STREAMS = 4;
+constexpr uint32_t RT_NOALLOC_MAX_RAYS = 1u << 16, RT_NOALLOC_MAX_DEPTH = 1022;  // limits of rt_colour_at_noalloc
 constexpr uint32_t PER_LANE_MIN_UNITS = 512;  // trees above this many 64-byte units are walked lane by lane
 
 struct rt_scene {
@@ -2598,7 +2643,8 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     A.out_rgb = nullptr; A.out_rgb8 = nullptr; A.out_offset = 0;
     hipLaunchKernelGGL(k_chunk_begin, dim3((n_levels + 1 + 255) / 256), dim3(256), 0, st, w.levels, n_levels + 1, first.n,
                        w.counters);
-    HIP_TRY(hipEventRecord(w.ev[4 * slot + 0], st));
+    const bool timed = w.ev.size() >= 4 * (slot + 1);  // the allocation-free entry point brings no events
+    if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 0], st));
     for (uint32_t level = 0; level < n_levels; level++) {
         A.level = level;
         A.depth_remaining = depth - level;
@@ -2609,7 +2655,7 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     }
     tot.trace_launches += n_levels;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(w.ev[4 * slot + 1], st));
+    if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 1], st));
 
     if (s->has_area) {
         // number the shade points in the reference's rng order and step the row generators to them
@@ -2669,14 +2715,14 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         }
     }
     if (!shadows_queued && !fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
-    HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
+    if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
         if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
         if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
         else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, st, s->dev, A);
     }
-    HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
+    if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
     hipLaunchKernelGGL(k_chunk_end, dim3(1), dim3(STAT_SHARDS), 0, st, w.levels, n_levels, w.counters, w.stats,
                        w.status + slot);
     HIP_TRY(hipGetLastError());
@@ -2778,7 +2824,8 @@ uint32_t rt_max_container_list(void) { return CONT_CAP; }
 
 int rt_init(int device) {
     HIP_TRY(hipSetDevice(device));
-    return RT_OK;
+    unsigned char* p = nullptr;
+    return scratch_of_current_device(&p);  // rt_colour_at_noalloc's memory on this GPU
 }
 
 int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
@@ -3336,6 +3383,69 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
     }
     (void)hipFree(d_out);
     return rc;
+}
+
+uint32_t rt_noalloc_max_rays(void) { return RT_NOALLOC_MAX_RAYS; }
+
+// rt_colour_at with every device buffer carved out of the static `scratch` array: no hipMalloc, no
+// hipFree, no stream or event creation.  Same kernels, same results.
+int rt_colour_at_noalloc(rt_scene* s, uint32_t n, const double* rays_dev, uint32_t depth, double* out_rgb_dev) {
+    if (!s || (n && (!rays_dev || !out_rgb_dev))) return fail(RT_ERR_INVALID, "null argument");
+    if (n == 0) return RT_OK;
+    if (n > RT_NOALLOC_MAX_RAYS)
+        return fail(RT_ERR_CAPACITY, "rt_colour_at_noalloc takes at most " + std::to_string(RT_NOALLOC_MAX_RAYS) +
+                                         " rays per call (the static scratch is " + std::to_string(SCRATCH_BYTES >> 20) + " MiB)");
+    if (depth > RT_NOALLOC_MAX_DEPTH)
+        return fail(RT_ERR_CAPACITY, "rt_colour_at_noalloc takes a depth of at most " + std::to_string(RT_NOALLOC_MAX_DEPTH));
+    if (s->has_area)
+        return fail(RT_ERR_UNSUPPORTED, "rt_colour_at_noalloc: a scene with an area light sizes its rng-order buffers from "
+                                        "device-side counts, which needs allocations");
+    if (!s->spawns) depth = 0;
+    HIP_TRY(hipSetDevice(s->device));
+    unsigned char* base = nullptr;
+    int rc = scratch_of_current_device(&base);
+    if (rc != RT_OK) return rc;
+
+    // carve the scratch: fixed-size parts first, the record columns take the rest
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = base + off; off += (bytes + 255) & ~(size_t)255; return p; };
+    Workspace w;                      // lives on this stack frame only; owns nothing
+    w.stream = nullptr;               // the null stream
+    w.counters = (Counters*)take(sizeof(Counters));
+    w.stats = (StatShard*)take(STAT_SHARDS * sizeof(StatShard));
+    w.status = (ChunkStatus*)take(sizeof(ChunkStatus));
+    w.levels = (LevelState*)take(((size_t)RT_NOALLOC_MAX_DEPTH + 2) * sizeof(LevelState));
+    const size_t per_rec = REC_BYTES + 8 * (size_t)s->dev.n_lights;
+    const size_t cap = ((SCRATCH_BYTES - off) / per_rec) & ~(size_t)63;  // 64 records = 512 bytes of a f64 column
+    if (cap < n) return fail(RT_ERR_CAPACITY, "the static scratch cannot hold one record per ray for this scene's lights");
+    double** dp[16] = {&w.R.ox, &w.R.oy, &w.R.oz, &w.R.dx, &w.R.dy, &w.R.dz, &w.R.px, &w.R.py,
+                       &w.R.pz, &w.R.nx, &w.R.ny, &w.R.nz, &w.R.reflectance, &w.R.r, &w.R.g, &w.R.b};
+    for (auto pp : dp) *pp = (double*)take(cap * sizeof(double));
+    w.intensity = (double*)take(cap * s->dev.n_lights * sizeof(double));
+    uint32_t** up[4] = {&w.R.hit_pos, &w.R.child_refl, &w.R.child_refr, &w.R.order};
+    for (auto pp : up) *pp = (uint32_t*)take(cap * sizeof(uint32_t));
+    if (off > SCRATCH_BYTES) return fail(RT_ERR_CAPACITY, "static scratch layout overflow");
+    w.rec_cap = cap;
+
+    // the array keeps the previous call's contents: the statistics lines must start at zero (the
+    // level table and the error word are reset by k_chunk_begin)
+    constexpr uint32_t stat_words = STAT_SHARDS * sizeof(StatShard) / sizeof(unsigned long long);
+    hipLaunchKernelGGL(k_zero_words, dim3((stat_words + 255) / 256), dim3(256), 0, w.stream, (unsigned long long*)w.stats, stat_words);
+    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, w.stream, rays_dev, n, w.R);
+    LevelArgs A{};
+    A.part_world = 1;
+    RunTotals tot;
+    FirstLevel first{false, n, 1, n, nullptr};
+    rc = queue_chunk_dispatch(s, w, A, first, depth, out_rgb_dev, nullptr, 0, 0, tot);
+    hipError_t e = hipStreamSynchronize(w.stream);  // also after a failed queueing: nothing may still write into the scratch
+    if (rc != RT_OK) return rc;
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    ChunkStatus st{};
+    HIP_TRY(hipMemcpy(&st, w.status, sizeof st, hipMemcpyDeviceToHost));
+    if (st.error & 1u)
+        return fail(RT_ERR_CAPACITY, "rt_colour_at_noalloc: the rays spawned more than the " + std::to_string(cap) +
+                                         " ray records the static scratch holds; pass fewer rays per call or a smaller depth");
+    return check_status(st);
 }
 
 int rt_probe(rt_scene* s, uint32_t n, const double* rays, double* out) {
