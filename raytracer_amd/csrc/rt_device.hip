@@ -81,6 +81,12 @@ constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one st
 #ifndef TRACE_BLOCK
 #define TRACE_BLOCK 256   // threads per k_trace block: one append atomic per block and step
 #endif
+#ifndef PREFETCH_RAY
+#define PREFETCH_RAY 1    // k_trace fetches the next step's ray before this step's shadow walk
+#endif
+#ifndef FUSE_LIGHTING
+#define FUSE_LIGHTING 0   // 1: k_trace of scenes without an area light also computes Material::lighting and k_fold only adds the children (measured slower: the lighting does not fit k_trace's registers)
+#endif
 #ifndef REC_CAP
 #define REC_CAP 8         // candidates per lane recorded in LDS during the closest-hit walk (16 B each)
 #endif
@@ -143,6 +149,11 @@ struct Ray { V3 o, d; };
 //       its inverse lives in `xform` (meshes share one matrix, so a wave transforms its rays once
 //       per matrix, not once per triangle) and its vertex normals in `tri_normals`.
 constexpr uint32_t K_GROUP = 6, K_CSG = 7;
+// Device-only: a "cluster" header (1 unit) ahead of a run of sibling leaves that all have bounding
+// spheres.  w1 = unit position after the run, w2 = algorithmic FLOP of the run's tests for one ray,
+// bits 11 / 16 as for a leaf (set when every member has them); its own bounding sphere, which holds
+// the members' spheres, sits in `cull`.  A ray that cannot reach it skips the whole run with one test.
+constexpr uint32_t K_CLUSTER = 8;
 constexpr uint32_t MESH_BIT = 1u << 12;  // group header w0: the subtree is a mesh with a hierarchy of its own (w2 root, w3 matrix)
 constexpr uint32_t MESH_ALL_CAST = 1u << 14, MESH_NONE_CAST = 1u << 15;  // mesh root: every / no triangle casts a shadow
 constexpr uint32_t NESTED_BIT = 1u << 13;
@@ -380,8 +391,14 @@ DEV bool triangle_hit(const Ray& r, V3 p1, V3 e1, V3 e2, double& t, double& u, d
 // What a lane's walks add to the statistics: algorithmic FLOP (`+=` takes those), and for the
 // meshes' own hierarchies the nodes visited and triangles tested (their fetches: 128 and 80 bytes).
 struct Work {
-    uint32_t flops, nodes, tris;
-    DEV Work& operator+=(uint32_t f) { flops += f; return *this; }
+    // `flops` is a sum over the wave, kept in scalar registers: add() is called where the wave's lanes
+    // are together and counts f once for every lane for which `cond` holds (f must be the same in all
+    // lanes - a constant, or data of a node the whole wave is at).  Code in which the lanes have gone
+    // separate ways (the lane walk, a mesh's hierarchy) counts per lane.
+    unsigned long long flops;
+    uint32_t lane_flops, nodes, tris;
+    DEV void add(uint32_t f, bool cond) { flops += (unsigned long long)f * (uint32_t)__popcll(__ballot(cond)); }
+    DEV void add_lane(uint32_t f) { lane_flops += f; }
 };
 struct Walk {
     double t;              // closest hit so far
@@ -411,7 +428,12 @@ struct ContBuf {
     uint32_t* pos;
     uint32_t* cls;
     int stride, cap;
-    DEV void put(int k, double tt, uint32_t p, uint32_t c) const { t[k * stride] = tt; pos[k * stride] = p; cls[k * stride] = c; }
+    uint32_t off;  // this lane's column: entry k is at k * stride + off (the pointers themselves may be the same for all lanes)
+    DEV int at(int k) const { return k * stride + (int)off; }
+    DEV void put(int k, double tt, uint32_t p, uint32_t c) const { t[at(k)] = tt; pos[at(k)] = p; cls[at(k)] = c; }
+    DEV double& T(int k) const { return t[at(k)]; }
+    DEV uint32_t& P(int k) const { return pos[at(k)]; }
+    DEV uint32_t& C(int k) const { return cls[at(k)]; }
 };
 // The first entries go to LDS (lanes interleaved, stride = block size), the rare rest to
 // lane-private scratch at the same index.
@@ -424,9 +446,9 @@ struct RecordBuf {
     DEV void put(int k, double tt, uint32_t p, uint32_t c) const {
         if (k < fast.cap) fast.put(k, tt, p, c); else big.put(k, tt, p, c);
     }
-    DEV double t_at(int k) const { return k < fast.cap ? fast.t[k * fast.stride] : big.t[k * big.stride]; }
-    DEV uint32_t pos_at(int k) const { return k < fast.cap ? fast.pos[k * fast.stride] : big.pos[k * big.stride]; }
-    DEV uint32_t cls_at(int k) const { return k < fast.cap ? fast.cls[k * fast.stride] : big.cls[k * big.stride]; }
+    DEV double t_at(int k) const { return k < fast.cap ? fast.T(k) : big.T(k); }
+    DEV uint32_t pos_at(int k) const { return k < fast.cap ? fast.P(k) : big.P(k); }
+    DEV uint32_t cls_at(int k) const { return k < fast.cap ? fast.C(k) : big.C(k); }
 };
 // Shadow rays only need the closest hit below the light's distance: their walk starts with that
 // distance as the bound to beat (position LIMIT = nothing found yet), so everything beyond the
@@ -498,6 +520,22 @@ DEV void close_csgs(const DevScene& S, uint32_t i, double* ct, uint32_t* cl, uin
     }
 }
 
+// Device-only culling with a bounding sphere (centre c, radius^2 r2, world space): the ray cannot
+// reach it, or reach it before its closest hit so far, or (`skip_behind`: shapes that are always
+// entered and left) it lies wholly behind the origin.  Intersections inside such a sphere can
+// neither become the hit nor sort before it.
+DEV bool sphere_culled(const Ray& ray, V3 c, double r2, bool skip_behind, const Walk& w) {
+    const V3 oc = c - ray.o;
+    const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
+    const bool outside = cc > r2;
+    const bool miss = outside && b * b < dd * (cc - r2);
+    const bool behind = outside && b < 0.0 && skip_behind;
+    // entry parameter >= b/dd - r/|d|: beyond the hit so far iff b - t*dd > r*|d|, squared to avoid |d|
+    const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
+    const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
+    return miss || behind || beyond;
+}
+
 // World::intersect + Object::intersect for every lane of the wave at once
 // (world.rs:90-106, object/mod.rs:100-106, object/group/mod.rs:29-47,
 // object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
@@ -517,8 +555,9 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     int clen = 0, cs_top = 0;
     (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
 
-    // `cls` is the structural-equality class of the leaf at unit position p
-    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t lmat) {
+    // `cls` is the structural-equality class of the leaf at unit position p.  Only the hit's distance
+    // and position are tracked here; its header words are read back when the walk is over.
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
         if (on) {
             if (tt != tt) w.nan_seen = true;
             const bool below = w.pos == NONE || tt < w.t;
@@ -527,18 +566,17 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                     if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
                 }
             }
-            if (tt > 0.0 && below) { w.t = tt; w.pos = p; w.w0 = lw0; w.mat = lmat; w.cls = cls; }
+            if (tt > 0.0 && below) { w.t = tt; w.pos = p; }
             w.arrival++;
         }
     };
 
-    // object-space ray of the mesh matrix most recently used (triangles)
-    uint32_t cur_xform = NONE;
-    Ray tri_ray = ray;
-
     uint32_t i = 0;
     for (;;) {
-        if constexpr (HAS_CSG) close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit, Buf::enabled && record);
+        if constexpr (HAS_CSG) {
+            auto emit_csg = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t, uint32_t) { emit(on, tt, p, cls); };
+            close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit_csg, Buf::enabled && record);
+        }
         if (i >= n) break;
         bool act = skip_until <= i;
         if (__ballot(act) == 0ull) {
@@ -561,11 +599,23 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
         const uint32_t w0 = (uint32_t)__double2loint(q[0]), w1 = (uint32_t)__double2hiint(q[0]);
         const uint32_t w2 = (uint32_t)__double2loint(q[1]), w3 = (uint32_t)__double2hiint(q[1]);
         const uint32_t kind = w0 & 0xFFu;
+        if (kind == K_CLUSTER) {
+            if constexpr (CULL) {
+                // lanes that cannot use anything in the run pass over it (the reference would have run
+                // its tests: they still count as algorithmic work); when that is every lane, the
+                // ballot at the top of the loop jumps there
+                const bool pass_over = act && sphere_culled(ray, mk(cs[0], cs[1], cs[2]), cs[4], (w0 & (record ? 1u << 11 : 1u << 16)) != 0, w);
+                if (pass_over) skip_until = w1;
+                if (count) flops.add(w2, pass_over);
+            }
+            i += 1;
+            continue;
+        }
         if (kind >= K_GROUP) {
             // Group or csg: cull by the stored box (group/mod.rs:30-32, csg/mod.rs:89-91)
             double t0, t1;
             bool hit = box_intersect(ray, q[2], q[3], q[4], q[5], q[6], q[7], t0, t1);
-            if (act && count) flops += F_BOX;
+            if (count) flops.add(F_BOX, act);
             uint32_t end = w1;
             // Beyond the reference's test: a box entered after the closest hit so far cannot hold a
             // closer one (nor anything that sorts before it), so its subtree is skipped as well.  Only
@@ -597,19 +647,11 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             // no lane's ray can reach it, or reach it before its closest hit so far, or (for shapes
             // that are always entered and left) it lies wholly behind the origin.  Such intersections
             // can neither become the hit nor sort before it, so the test is skipped for the wave.
-            const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
-            const double r2 = cs[4];
-            const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
-            const bool outside = cc > r2;
-            const bool miss = outside && b * b < dd * (cc - r2);
-            const bool behind = outside && b < 0.0 && (w0 & (record ? 1u << 11 : 1u << 16));
-            // entry parameter >= b/dd - r/|d|: beyond the hit so far iff b - t*dd > r*|d|, squared to avoid |d|
-            const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
-            const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
-            if (__ballot(act && !(miss || behind || beyond)) == 0ull) {
+            const bool culled = sphere_culled(ray, mk(cs[0], cs[1], cs[2]), cs[4], (w0 & (record ? 1u << 11 : 1u << 16)) != 0, w);
+            if (__ballot(act && !culled) == 0ull) {
                 // the reference would have run the test: it still counts as algorithmic work
-                if (act && count)
-                    flops += F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE);
+                if (count)
+                    flops.add(F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE), act);
                 i += 2;
                 continue;
             }
@@ -617,31 +659,58 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
         LeafHits h;
         h.n = 0;
         uint32_t f = F_XFORM;
+        int max_hits = 4;
         if (kind == RT_TRIANGLE) {
-            uint32_t xf = (uint32_t)__double2loint(q[2]);
-            if (xf != cur_xform) {  // wave-uniform: one transform per mesh matrix
-                cur_xform = xf;
-                tri_ray = to_object_u(S.xform, xf * 12, ray);
-            }
+            max_hits = 1;
+            // the mesh's matrix through scalar loads; the transformed ray is not kept from one triangle
+            // to the next: twelve registers held across the whole walk cost more than the arithmetic
+            const Ray tri_ray = to_object_u(S.xform, (uint32_t)__double2loint(q[2]) * 12, ray);
             V3 p1 = mk(q[4], q[5], q[6]), e1 = mk(q[7], q[8], q[9]), e2 = mk(q[10], q[11], q[12]);
             double t, u, v;
             if (triangle_hit(tri_ray, p1, e1, e2, t, u, v)) { h.t[0] = t; h.n = 1; }
             f += F_TRI;
+        } else if (kind == RT_PLANE) {
+            // only the y components of the object-space ray matter (shape.rs:49-57, plane.rs:17-23)
+            const double oy = q[6] * ray.o.x + q[7] * ray.o.y + q[8] * ray.o.z + q[9];
+            const double dy = q[6] * ray.d.x + q[7] * ray.d.y + q[8] * ray.d.z;
+            bool want = !approx0(dy);
+#ifndef PLANE_PRETEST
+#define PLANE_PRETEST 1
+#endif
+            if (PLANE_PRETEST && CULL && !(Buf::enabled && record)) {
+                // A walk that records nothing only uses an intersection with 0 < t < the closest so far:
+                // the signs settle the first, a product (with the culling margin) the second, and most
+                // rays are done without the division.  NaNs go on to the division and are reported.
+                const bool unknown = oy != oy || dy != dy;
+                const bool ahead = (oy < 0.0) == (dy > 0.0) && oy != 0.0;  // t > 0
+                const bool within = w.pos == NONE || !(fabs(oy) > (w.t * (1.0 + CULL_REL) + CULL_ABS) * fabs(dy));
+                // Inside a csg an intersection behind the origin, however far, still flips the csg's
+                // inside state for everything in front of it.
+                bool behind_matters = false;
+                if constexpr (HAS_CSG) behind_matters = cs_top > 0;
+                want = want && (unknown || (ahead ? within : behind_matters));
+            }
+            if (act && want) { h.t[0] = -oy / dy; h.n = 1; }
+            f += F_PLANE;
+            max_hits = 1;
         } else {
             Ray r;  // Shape::intersect's ray in object space (shape.rs:49-57), rows 0-2 of the inverse in q[2..13]
             r.o = mk(q[2] * ray.o.x + q[3] * ray.o.y + q[4] * ray.o.z + q[5], q[6] * ray.o.x + q[7] * ray.o.y + q[8] * ray.o.z + q[9],
                      q[10] * ray.o.x + q[11] * ray.o.y + q[12] * ray.o.z + q[13]);
             r.d = mk(q[2] * ray.d.x + q[3] * ray.d.y + q[4] * ray.d.z, q[6] * ray.d.x + q[7] * ray.d.y + q[8] * ray.d.z,
                      q[10] * ray.d.x + q[11] * ray.d.y + q[12] * ray.d.z);
-            if (kind == RT_SPHERE) { sphere_hits(r, h); f += F_SPHERE; }
-            else if (kind == RT_PLANE) { plane_hits(r, h); f += F_PLANE; }
-            else if (kind == RT_CUBE) { cube_hits(r, h); f += F_BOX; }
+            if (kind == RT_SPHERE) { sphere_hits(r, h); f += F_SPHERE; max_hits = 2; }
+            else if (kind == RT_CUBE) { cube_hits(r, h); f += F_BOX; max_hits = 2; }
             else if (kind == RT_CYLINDER) { cylinder_hits(r, q[14], q[15], (w0 >> 9) & 1u, h); f += F_CYL; }
             else { cone_hits(r, q[14], q[15], (w0 >> 9) & 1u, h); f += F_CONE; }
         }
-        if (act && count) flops += f;
+        if (count) flops.add(f, act);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+#ifndef UNIFORM_HITS
+#define UNIFORM_HITS 1
+#endif
+            if (UNIFORM_HITS && k >= max_hits) break;  // wave-uniform: the node's kind bounds its intersections
             bool on = act && k < h.n;
             if constexpr (HAS_CSG) {
                 if (on && cs_top > 0) {
@@ -649,9 +718,14 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                     on = false;
                 }
             }
-            emit(on, h.t[k], i, w3, w0, w1);
+            emit(on, h.t[k], i, w3);
         }
         i += 2;
+    }
+    // the hit leaf's header words (shape, casts_shadow, closed; material; class)
+    if (w.pos < LIMIT) {
+        const uint32_t* lr = S.stream + (size_t)w.pos * 16;
+        w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
     }
 }
 
@@ -743,7 +817,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
             const uint32_t pos = (uint32_t)__double2loint(td[9]);
             double t, u, v;
             const bool got = triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
-            if (count) { flops += F_XFORM + F_TRI; flops.tris++; }
+            if (count) { flops.add_lane(F_XFORM + F_TRI); flops.tris++; }
             if (got) {
                 if (t != t) w.nan_seen = true;
                 w.arrival++;
@@ -766,7 +840,7 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
 #pragma unroll
             for (int k = 0; k < 12; k++) b[k] = nd[k];
             const uint32_t c0 = (uint32_t)__double2loint(nd[12]), c1 = (uint32_t)__double2hiint(nd[12]);
-            if (count) { flops += 2 * F_BOX; flops.nodes++; }
+            if (count) { flops.add_lane(2 * F_BOX); flops.nodes++; }
             double near_[2];
             bool hit_[2];
 #pragma unroll
@@ -856,10 +930,18 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
         const uint32_t w0 = (uint32_t)__double2loint(u0[0]), w1 = (uint32_t)__double2hiint(u0[0]);
         const uint32_t w2 = (uint32_t)__double2loint(u0[1]), w3 = (uint32_t)__double2hiint(u0[1]);
         const uint32_t kind = w0 & 0xFFu;
-        if (act && kind >= K_GROUP) {
+        if (act && kind == K_CLUSTER) {
+            bool culled = false;
+            if constexpr (CULL) {
+                const double* cs = S.cull + (size_t)i * 6;
+                culled = sphere_culled(ray, mk(cs[0], cs[1], cs[2]), cs[4], (w0 & (record ? 1u << 11 : 1u << 16)) != 0, w);
+                if (culled && count) flops.add_lane(w2);
+            }
+            i = culled ? w1 : i + 1;
+        } else if (act && kind >= K_GROUP) {
             double t0, t1;
             bool hit = box_intersect(ray, u0[2], u0[3], u0[4], u0[5], u0[6], u0[7], t0, t1);
-            if (count) flops += F_BOX;
+            if (count) flops.add_lane(F_BOX);
             if (CULL && kind == K_GROUP && (w0 & GROUP_SOUND) && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             uint32_t next = hit ? i + 1 : w1;
             if constexpr (CULL) {
@@ -894,17 +976,9 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             bool culled = false;
             if (CULL && (w0 & (1u << 10))) {  // see the wave-uniform walk
                 const double* cs = S.cull + (size_t)i * 6;
-                const V3 oc = mk(cs[0], cs[1], cs[2]) - ray.o;
-                const double r2 = cs[4];
-                const double b = dot(oc, ray.d), cc = dot(oc, oc), dd = dot(ray.d, ray.d);
-                const bool outside = cc > r2;
-                const bool miss = outside && b * b < dd * (cc - r2);
-                const bool behind = outside && b < 0.0 && (w0 & (record ? 1u << 11 : 1u << 16));
-                const double past = b - (w.t * (1.0 + CULL_REL) + CULL_ABS) * dd;
-                const bool beyond = w.pos != NONE && past > 0.0 && past * past > r2 * dd;
-                culled = miss || behind || beyond;
+                culled = sphere_culled(ray, mk(cs[0], cs[1], cs[2]), cs[4], (w0 & (record ? 1u << 11 : 1u << 16)) != 0, w);
                 if (culled && count)
-                    flops += F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE);
+                    flops.add_lane(F_XFORM + (kind == RT_SPHERE ? F_SPHERE : kind == RT_CUBE ? F_BOX : kind == RT_CYLINDER ? F_CYL : F_CONE));
             }
             if (!culled) {
                 LeafHits h;
@@ -932,7 +1006,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                     else if (kind == RT_CYLINDER) { cylinder_hits(r, recd[14], recd[15], (w0 >> 9) & 1u, h); f += F_CYL; }
                     else { cone_hits(r, recd[14], recd[15], (w0 >> 9) & 1u, h); f += F_CONE; }
                 }
-                if (count) flops += f;
+                if (count) flops.add_lane(f);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     bool on = k < h.n;
@@ -1037,15 +1111,34 @@ DEV V3 pattern_eval(PatTables S, uint32_t root, V3 object_point) {
 // One record per traced ray, kept as a structure of arrays over the records of a chunk so that a
 // wave's loads and stores are contiguous.  The levels of the recursion occupy consecutive index
 // ranges; a spawned ray is written straight into its own record.
+// Records are laid out in groups of 64 (one wave's worth): inside a group every column is a
+// contiguous run (512 bytes of f64, 256 of u32), so a wave's loads and stores stay coalesced, and a
+// record's columns lie within one 9 KB stretch of memory instead of twenty places gigabytes apart
+// (one page to translate per wave and step, and the columns are reached by immediate offsets from
+// one address).
+constexpr size_t REC_GROUP = 64, REC_GROUP_BYTES = REC_GROUP * (16 * sizeof(double) + 4 * sizeof(uint32_t));
+template <class T, uint32_t OFFSET>
+struct RecColumn {
+    unsigned char* base;
+    __host__ __device__ __forceinline__ T& operator[](size_t i) const {
+        return *(T*)(base + (i / REC_GROUP) * REC_GROUP_BYTES + OFFSET + (i % REC_GROUP) * sizeof(T));
+    }
+};
 struct Recs {
-    double *ox, *oy, *oz, *dx, *dy, *dz;  // the ray (primary rays store the direction only)
-    double *px, *py, *pz;                  // over_point of the hit
-    double *nx, *ny, *nz;                  // normal at the hit
-    double *reflectance;                   // schlick value, where the material is reflective and transparent
-    double *r, *g, *b;                     // colour_at of the ray, filled bottom-up
-    uint32_t *hit_pos;                     // unit position of the hit leaf, NONE for a miss
-    uint32_t *child_refl, *child_refr;     // record of the spawned rays or NONE (valid for hits)
-    uint32_t *order;                       // area lights: subtree size, then position in the row's rng order
+    unsigned char* base;  // capacity: a multiple of REC_GROUP records
+#define RT_COL(name, k) __host__ __device__ __forceinline__ RecColumn<double, (k) * 512u> name() const { return {base}; }
+    RT_COL(ox, 0) RT_COL(oy, 1) RT_COL(oz, 2) RT_COL(dx, 3) RT_COL(dy, 4) RT_COL(dz, 5)  // the ray (primary rays store the direction only)
+    RT_COL(px, 6) RT_COL(py, 7) RT_COL(pz, 8)      // over_point of the hit
+    RT_COL(nx, 9) RT_COL(ny, 10) RT_COL(nz, 11)    // normal at the hit
+    RT_COL(reflectance, 12)                        // schlick value, where the material is reflective and transparent
+    RT_COL(r, 13) RT_COL(g, 14) RT_COL(b, 15)      // colour_at of the ray, filled bottom-up
+#undef RT_COL
+#define RT_UCOL(name, k) __host__ __device__ __forceinline__ RecColumn<uint32_t, 8192u + (k) * 256u> name() const { return {base}; }
+    RT_UCOL(hit_pos, 0)      // unit position of the hit leaf, NONE for a miss
+    RT_UCOL(child_refl, 1)   // record of the spawned rays or NONE (valid for hits)
+    RT_UCOL(child_refr, 2)
+    RT_UCOL(order, 3)        // area lights: subtree size, then position in the row's rng order
+#undef RT_UCOL
 };
 constexpr size_t REC_BYTES = 16 * sizeof(double) + 4 * sizeof(uint32_t);
 
@@ -1057,13 +1150,13 @@ struct Counters {
 struct LevelState { uint32_t n, base; };
 struct ChunkStatus {
     uint32_t error, total_recs, levels, pad;
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;  // this chunk's statistics
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris, flop_fold;  // this chunk's statistics
 };
 // Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
 // and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
 constexpr uint32_t STAT_SHARDS = 256;
 struct __attribute__((aligned(64))) StatShard {
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris, flop_fold;
 #ifdef RT_PHASE_TIMERS
     unsigned long long phase[8];  // shader-clock ticks per k_trace phase, summed over waves
 #endif
@@ -1177,22 +1270,22 @@ struct N1N2 { double n1, n2; };
 // The containers list is built in place over the entries already consumed.
 DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, int n, double hit_t, uint32_t hit_pos,
                         uint32_t hit_cls) {
-    const int S = cb.stride;
+    (void)cb.stride;
     int m = 0;
     for (int a = 0; a < n; a++) {
-        double ta = cb.t[a * S];
+        double ta = cb.T(a);
         if (ta < hit_t) {
-            if (m != a) cb.put(m, ta, cb.pos[a * S], cb.cls[a * S]);
+            if (m != a) cb.put(m, ta, cb.P(a), cb.C(a));
             m++;
         }
     }
     // stable insertion sort by t (List::sort, intersection/list.rs:39-50)
     for (int a = 1; a < m; a++) {
-        double ta = cb.t[a * S];
-        if (!(cb.t[(a - 1) * S] > ta)) continue;
-        uint32_t la = cb.pos[a * S], ca = cb.cls[a * S];
+        double ta = cb.T(a);
+        if (!(cb.T((a - 1)) > ta)) continue;
+        uint32_t la = cb.P(a), ca = cb.C(a);
         int b = a - 1;
-        while (b >= 0 && cb.t[b * S] > ta) { cb.put(b + 1, cb.t[b * S], cb.pos[b * S], cb.cls[b * S]); b--; }
+        while (b >= 0 && cb.T(b) > ta) { cb.put(b + 1, cb.T(b), cb.P(b), cb.C(b)); b--; }
         cb.put(b + 1, ta, la, ca);
     }
     int cn = 0;  // containers are entries [0, cn) of pos/cls, oldest first; cn <= a
@@ -1200,22 +1293,22 @@ DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, i
     for (int a = 0; a <= m; a++) {
         double t = hit_t;
         uint32_t lf = hit_pos, cls = hit_cls;
-        if (a < m) { t = cb.t[a * S]; lf = cb.pos[a * S]; cls = cb.cls[a * S]; }
+        if (a < m) { t = cb.T(a); lf = cb.P(a); cls = cb.C(a); }
         const bool is_hit = (a == m) || (cls == hit_cls && approx_eq(t, hit_t));
         int k = 0;
-        while (k < cn && cb.cls[k * S] != cls) k++;
+        while (k < cn && cb.C(k) != cls) k++;
         if (is_hit) {
-            n1_pos = cn == 0 ? NONE : cb.pos[(cn - 1) * S];
+            n1_pos = cn == 0 ? NONE : cb.P((cn - 1));
             if (k == cn) n2_pos = lf;                                   // appended: the hit object itself
-            else if (k < cn - 1) n2_pos = cb.pos[(cn - 1) * S];         // removed below the top
-            else n2_pos = cn >= 2 ? cb.pos[(cn - 2) * S] : NONE;        // the top was removed
+            else if (k < cn - 1) n2_pos = cb.P((cn - 1));         // removed below the top
+            else n2_pos = cn >= 2 ? cb.P((cn - 2)) : NONE;        // the top was removed
             break;
         }
         if (k < cn) {
-            for (int j = k; j + 1 < cn; j++) { cb.pos[j * S] = cb.pos[(j + 1) * S]; cb.cls[j * S] = cb.cls[(j + 1) * S]; }
+            for (int j = k; j + 1 < cn; j++) { cb.P(j) = cb.P((j + 1)); cb.C(j) = cb.C((j + 1)); }
             cn--;
         } else {
-            cb.pos[cn * S] = lf; cb.cls[cn * S] = cls; cn++;
+            cb.P(cn) = lf; cb.C(cn) = cls; cn++;
         }
     }
     N1N2 r;
@@ -1234,7 +1327,7 @@ DEV N1N2 container_walk(const uint32_t* stream, const double* mat, ContBuf cb, i
 DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf cb, int n, bool need, double hit_t,
                              uint32_t hit_pos, uint32_t hit_cls, bool few_classes) {
     constexpr int N = REC_CAP;
-    const int S = cb.stride;
+    (void)cb.stride;
     // the longest list of the wave bounds every loop below (wave-uniform, so the unrolled
     // iterations past it are skipped by a scalar branch)
     int nmax = 0;
@@ -1248,7 +1341,7 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
     for (int k = 0; k < N; k++) {
         t[k] = 0.0; p[k] = NONE; c[k] = NONE; v[k] = false;
         if (k < nmax) {
-            t[k] = cb.t[k * S]; p[k] = cb.pos[k * S]; c[k] = cb.cls[k * S];
+            t[k] = cb.T(k); p[k] = cb.P(k); c[k] = cb.C(k);
             v[k] = need && k < n && t[k] < hit_t;
         }
     }
@@ -1335,7 +1428,7 @@ DEV N1N2 container_walk_regs(const uint32_t* stream, const double* mat, ContBuf 
 // Lane-private scratch buffers make this one big; keep it out of line.
 __device__ __noinline__ N1N2 container_walk_scratch(const uint32_t* stream, const double* mat, double* ts, uint32_t* poss,
                                                     uint32_t* clss, int n, double hit_t, uint32_t hit_pos, uint32_t hit_cls) {
-    ContBuf cb = {ts, poss, clss, 1, CONT_CAP};
+    ContBuf cb = {ts, poss, clss, 1, CONT_CAP, 0u};
     return container_walk(stream, mat, cb, n, hit_t, hit_pos, hit_cls);
 }
 
@@ -1396,7 +1489,8 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
-                     Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE) {
+                     Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE,
+                     double* lds_out = nullptr) {
     if (__ballot(on) == 0ull) return;
     l_end = min(l_end, S.n_lights);  // a wave-uniform range of lights (all of them unless told otherwise)
     for (uint32_t l = l_begin; l < l_end; l++) {
@@ -1441,41 +1535,123 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             bool shadowed = moot;  // reported as intensity 0: k_shade then skips the light's loop as well
             if (cast && w.pos < LIMIT) shadowed = ((w.w0 >> 8) & 1u) && w.t < distance;
             if (!shadowed) unshadowed += 1.0;
-            if (on) { flops += F_SHADOW; n_shadow++; }
+            flops.add(F_SHADOW, on);
+            n_shadow += (uint32_t)__popcll(__ballot(on));
         }
         if (on) {
             double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
-            A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
+            // k_trace keeps the first lights' values in its block's LDS (entry l of this lane at l * TRACE_BLOCK)
+            if (lds_out && l < REC_CAP) lds_out[l * TRACE_BLOCK] = intensity;
+            else A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
         }
         if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
     }
 }
 
-// colour_at for every ray of one level, minus the shading and the recursion
-// (world.rs:33-49,129-177; intersection/mod.rs:45-109).
+// Colour::to_u8 (colour.rs:63-72): clamp, * 255, round half away from zero, NaN -> 0.
+DEV uint8_t to_u8(double c) {
+    if (c != c) return 0;
+    double cl = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+    return (uint8_t)round(cl * 255.0);
+}
+
+// pow() is by far the largest register user of the shading code; out of line it only costs its
+// registers while it runs.
+__device__ __noinline__ double shade_pow(double x, double y) { return pow(x, y); }
+
+// Material::lighting for one light (material.rs:47-87); `pat` is pattern_at(object, over_point)
+// (pattern/mod.rs:83-87), `intensity` the light's intensity_at for this point.  With an area light
+// `rng` stands at the first of intensity_at's draws for this light (world.rs:61-69) and is left
+// behind lighting's own draws.
+DEV V3 lighting_one(const DevScene& S, uint32_t l, V3 pat, double m_ambient, double m_diffuse, double m_specular,
+                    double m_shininess, V3 over, V3 normal, V3 eye, double intensity, Rng& rng, uint32_t& flops) {
+    // wave-uniform light data through the scalar cache
+    const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
+    const uint32_t samples = usteps * vsteps;
+    const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
+    const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
+    const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
+    const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
+    const V3 lint = is_area ? mk(cld(S.light, l * 12 + 9), cld(S.light, l * 12 + 10), cld(S.light, l * 12 + 11)) : uc;
+    if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
+    V3 col = cmul(pat, lint);
+    V3 ambient = col * m_ambient;
+    V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
+    // With intensity 0 the diffuse and specular sums are multiplied by zero (they are finite
+    // for a non-negative shininess): the loop is skipped, only its rng draws are taken.
+    const bool dark = intensity == 0.0 && m_shininess >= 0.0;
+    if (dark && is_area) rng_skip(rng, 2 * samples);
+    // A specular weight of zero makes every term of the specular sum (intensity * 0) * factor: for a
+    // factor in [0, 1] that is the same signed zero (or NaN) whatever the factor, so pow() is skipped.
+    const bool no_gloss = m_specular == 0.0 && m_shininess >= 0.0;
+    for (uint32_t k = 0; k < (dark ? 0u : samples); k++) {
+        V3 lp = l0;
+        if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
+            double r1 = rng_unit(rng);
+            V3 p = l0 + uc * ((double)(k % usteps) + r1);
+            double r2 = rng_unit(rng);
+            lp = p + vc * ((double)(k / usteps) + r2);
+        }
+        V3 lv = normalise(lp - over);
+        double ldn = dot(lv, normal);
+        if (ldn >= 0.0) {
+            diffuse = diffuse + (col * m_diffuse) * ldn;
+            V3 rv = -reflect(lv, normal);
+            double rde = dot(rv, eye);
+            if (rde > 0.0) {
+                double factor = (no_gloss && rde <= 1.0) ? 1.0 : shade_pow(rde, m_shininess);
+                specular = specular + (lint * m_specular) * factor;
+            }
+        }
+    }
+    flops += F_LIGHT * samples;
+    return ambient + ((diffuse + specular) / (double)samples) * intensity;
+}
+
+// shade_hit's sum (world.rs:72-86); a ray that was not spawned contributes black
+DEV V3 combine(V3 surface, V3 reflected, V3 refracted, double m_reflective, double m_transparency, double reflectance) {
+    if (m_reflective > 0.0 && m_transparency > 0.0) return surface + reflected * reflectance + refracted * (1.0 - reflectance);
+    return surface + reflected + refracted;
+}
+
+// colour_at for every ray of one level, minus the recursion (world.rs:33-49,129-177;
+// intersection/mod.rs:45-109).  With FUSED the kernel also casts the hit's shadow rays and computes
+// its surface colour (Material::lighting), so that only the sum with the spawned rays' colours is
+// left for k_fold; otherwise it stores the hit's geometry for k_shadow and k_shade.
 // Without CULL every walk is the reference's, test for test (a slow mode the others are checked against).
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool SHADOWS, bool CULL = true>
+//
+// The rays a block spawns in one step are appended to the next level together: one atomic on the
+// level's counter per block and step (a single word serialises at ~85 atomics per microsecond, so
+// per-wave atomics would), and inside the block's range the children are grouped by (object they
+// start on, reflected / refracted), so that the next level's waves hold rays that meet the same
+// objects and a test culled for one lane is more often culled for all 64.
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true>
 __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
-    if (A.counters->error & 1u) return;  // an earlier level ran out of records: the chunk is retried
-    const LevelState lv = A.levels[A.level];
-    const uint32_t n_rays = lv.n, rec_base = lv.base, next_rec_base = lv.base + lv.n;
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.levels[A.level + 1].base = next_rec_base;
+    constexpr uint32_t WAVES = TRACE_BLOCK / 64;
+    constexpr bool LIT = FUSED && FUSE_LIGHTING;  // the surface colour is computed here
     __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_hist[2][SPAWN_BINS], s_off[2][SPAWN_BINS];
-    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_base[2], s_abort;
+    // an earlier level ran out of records: the chunk is retried.  Blocks of this launch set the same
+    // bit when they end, so the decision is taken once per block.
+    if (threadIdx.x == 0) s_abort = A.counters->error & 1u;
     if (threadIdx.x < SPAWN_BINS) s_hist[0][threadIdx.x] = 0u;
     __syncthreads();
+    if (s_abort) return;
+    const LevelState lv = A.levels[A.level];
+    const uint32_t n_rays = lv.n, rec_base = lv.base, next_rec_base = lv.base + lv.n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.levels[A.level + 1].base = next_rec_base;
     double big_t[CONT_CAP];
     uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
     RecordBuf buf;
-    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, TRACE_BLOCK, REC_CAP};
-    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
+    buf.fast = {s_rec_t, s_rec_pos, s_rec_cls, TRACE_BLOCK, REC_CAP, threadIdx.x};  // block-wide bases, this lane's column
+    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP, 0u};
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     Work flops{}, flops_shadow{};
-    uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0;
+    uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0, flops_light = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
     // A lane-walked level with few rays spreads them over more waves (`lanes` active lanes in each, a
     // power of two): lanes of one wave at different kinds of node take turns, so a wave's walk costs
@@ -1487,9 +1663,24 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
 #endif
         while (lanes > 1 && n_rays <= (lanes / 2) * SPREAD_WAVES) lanes >>= 1;
     }
-    const uint32_t rays_per_step = (TRACE_BLOCK / 64) * lanes;
-    const uint32_t n_steps = PRIMARY ? (A.n_tiles + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64) : (n_rays + rays_per_step - 1) / rays_per_step;
+    const uint32_t rays_per_step = WAVES * lanes;
+    const uint32_t n_steps = PRIMARY ? (A.n_tiles + WAVES - 1) / WAVES : (n_rays + rays_per_step - 1) / rays_per_step;
     uint32_t parity = 0;
+    // The ray of the step after this one is requested before this step's shadow walk, so that its
+    // trip through memory (behind this step's stores) is over by the time the walk ends.
+    auto fetch_ray = [&](uint32_t step_) {
+        const uint32_t idx = step_ * rays_per_step + wave_in_block * lanes + lane;
+        const uint32_t r = rec_base + ((lane < lanes && idx < n_rays) ? idx : 0);
+        Ray f;
+        f.o = mk(A.R.ox()[r], A.R.oy()[r], A.R.oz()[r]);
+        f.d = mk(A.R.dx()[r], A.R.dy()[r], A.R.dz()[r]);
+        return f;
+    };
+    Ray fetched;
+    fetched.o = fetched.d = mk(0.0, 0.0, 0.0);
+    if constexpr (!PRIMARY && PREFETCH_RAY) {
+        if (blockIdx.x < n_steps) fetched = fetch_ray(blockIdx.x);
+    }
     for (uint32_t step = blockIdx.x; step < n_steps; step += gridDim.x, parity ^= 1u) {
     LOOP_FENCE();
     bool on;
@@ -1502,7 +1693,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     Ray ray;
     if constexpr (PRIMARY) {
         // an 8x8 pixel tile per wave
-        uint32_t tile = step * (TRACE_BLOCK / 64) + wave_in_block;
+        uint32_t tile = step * WAVES + wave_in_block;
         bool tile_ok = tile < A.n_tiles;
         uint32_t tx = tile_ok ? tile % A.tiles_x : 0, ty = tile_ok ? tile / A.tiles_x : 0;
         uint32_t x = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
@@ -1510,16 +1701,16 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
         rec_idx = on ? ly * A.width + x : 0;
         uint32_t gy = global_row(A, A.chunk_row0 + (on ? ly : 0));
         ray = ray_for_pixel(A, on ? x : 0, gy);
+        flops.add(F_PRIMARY, on);
         if (on) {
-            flops += F_PRIMARY;
-            A.R.dx[rec_idx] = ray.d.x; A.R.dy[rec_idx] = ray.d.y; A.R.dz[rec_idx] = ray.d.z;
+            if constexpr (!LIT) { A.R.dx()[rec_idx] = ray.d.x; A.R.dy()[rec_idx] = ray.d.y; A.R.dz()[rec_idx] = ray.d.z; }
         }
     } else {
         uint32_t idx = step * rays_per_step + wave_in_block * lanes + lane;
         on = lane < lanes && idx < n_rays;
         rec_idx = rec_base + (on ? idx : 0);
-        ray.o = mk(A.R.ox[rec_idx], A.R.oy[rec_idx], A.R.oz[rec_idx]);
-        ray.d = mk(A.R.dx[rec_idx], A.R.dy[rec_idx], A.R.dz[rec_idx]);
+        if constexpr (PREFETCH_RAY) ray = fetched;
+        else ray = fetch_ray(step);
     }
 
     PHASE(1);
@@ -1544,7 +1735,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
         if (need_cont && !small) {  // rare: continue in the lane-private buffer
             if (w.overflow) err |= 2u;
             for (int k = 0; k < REC_CAP; k++)
-                buf.big.put(k, buf.fast.t[k * TRACE_BLOCK], buf.fast.pos[k * TRACE_BLOCK], buf.fast.cls[k * TRACE_BLOCK]);
+                buf.big.put(k, buf.fast.T(k), buf.fast.P(k), buf.fast.C(k));
             nn = container_walk_scratch(S.stream, S.mat, big_t, big_pos, big_cls, w.n, hit_t, hit_pos, hit_cls);
         }
         if (need_cont) { n1 = nn.n1; n2 = nn.n2; }
@@ -1554,43 +1745,42 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     if (hit) {
         HitGeom g = hit_geometry(S.stream, S.xform, S.tri_normals, ray, hit_t, hit_pos);
         point = g.point; normal = g.normal;
-        flops += F_PREPARE;
     }
+    flops.add(F_PREPARE, hit);
     PHASE(5);
     const V3 eye = -ray.d;
     const V3 over = over_point_of(point, normal);
 
     // reflected_colour / refracted_colour spawn tests (world.rs:129-177)
-    bool spawn_refl = hit && A.depth_remaining > 0 && m_reflective > 0.0;
+    const bool spawn_refl = hit && A.depth_remaining > 0 && m_reflective > 0.0;
     bool spawn_refr = false;
-    V3 refr_dir = mk(0.0, 0.0, 0.0);
-    if (hit && A.depth_remaining > 0 && !approx0(m_transparency)) {
+    // the refracted direction is normal * a - eye * b (world.rs:171): the two factors are kept, not the vector
+    double refr_a = 0.0, refr_b = 0.0;
+    const bool refracts = hit && A.depth_remaining > 0 && !approx0(m_transparency);
+    flops.add(F_REFRACT, refracts);
+    if (refracts) {
         double n_ratio = n1 / n2;
         double cos_i = dot(eye, normal);
         double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
         if (!(sin2_t > 1.0)) {
             double cos_t = sqrt(1.0 - sin2_t);
-            refr_dir = normal * (n_ratio * cos_i - cos_t) - eye * n_ratio;
+            refr_a = n_ratio * cos_i - cos_t;
+            refr_b = n_ratio;
             spawn_refr = true;
         }
-        flops += F_REFRACT;
     }
     double reflectance = -1.0;
-    if (hit && m_reflective > 0.0 && m_transparency > 0.0) {
-        reflectance = schlick(eye, normal, n1, n2);
-        flops += F_SCHLICK;
-    }
+    const bool both = hit && m_reflective > 0.0 && m_transparency > 0.0;
+    flops.add(F_SCHLICK, both);
+    if (both) reflectance = schlick(eye, normal, n1, n2);
 
-    // Append the children to the next level: one atomic per block and step (the counter is a single
-    // word, so per-wave atomics would serialise).  Inside the block's range the children are grouped
-    // by (object they start on, reflected / refracted): the next level's waves then hold rays that
-    // meet the same objects, and a test culled for one lane is more often culled for all 64.  Which
-    // record a ray gets does not matter to anything else.
-    const uint32_t bin_base = (hit_pos >> 1) * 2u;
+    // Append the children to the next level (see above): ranks inside their groups, one scan and one
+    // atomic per block, then the stores.
+    const uint32_t bin_refl = ((hit_pos >> 1) * 2u) & (SPAWN_BINS - 1u), bin_refr = (bin_refl + 1u) & (SPAWN_BINS - 1u);
     uint32_t child_refl = NONE, child_refr = NONE, rank_refl = 0, rank_refr = 0;
     if (threadIdx.x < SPAWN_BINS) s_hist[parity ^ 1u][threadIdx.x] = 0u;  // for the next step (see the barriers)
-    if (spawn_refl) rank_refl = atomicAdd(&s_hist[parity][bin_base & (SPAWN_BINS - 1u)], 1u);
-    if (spawn_refr) rank_refr = atomicAdd(&s_hist[parity][(bin_base + 1u) & (SPAWN_BINS - 1u)], 1u);
+    if (spawn_refl) rank_refl = atomicAdd(&s_hist[parity][bin_refl], 1u);
+    if (spawn_refr) rank_refr = atomicAdd(&s_hist[parity][bin_refr], 1u);
     __syncthreads();
     if (threadIdx.x < 64) {  // exclusive scan of the bins by the first wave
         uint32_t c = threadIdx.x < SPAWN_BINS ? s_hist[parity][threadIdx.x] : 0u, incl = c;
@@ -1605,44 +1795,82 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     __syncthreads();
     PHASE(6);
     if (spawn_refl) {
-        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][bin_base & (SPAWN_BINS - 1u)] + rank_refl;
+        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][bin_refl] + rank_refl;
         if (c < A.rec_cap) {
             V3 d_ = reflect(ray.d, normal);  // intersection/mod.rs:105
-            A.R.ox[c] = over.x; A.R.oy[c] = over.y; A.R.oz[c] = over.z;
-            A.R.dx[c] = d_.x; A.R.dy[c] = d_.y; A.R.dz[c] = d_.z;
+            A.R.ox()[c] = over.x; A.R.oy()[c] = over.y; A.R.oz()[c] = over.z;
+            A.R.dx()[c] = d_.x; A.R.dy()[c] = d_.y; A.R.dz()[c] = d_.z;
             child_refl = c;
         } else err |= 1u;
     }
     if (spawn_refr) {
-        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][(bin_base + 1u) & (SPAWN_BINS - 1u)] + rank_refr;
+        uint32_t c = next_rec_base + s_base[parity] + s_off[parity][bin_refr] + rank_refr;
         if (c < A.rec_cap) {
             V3 o_ = under_point_of(point, normal);
-            A.R.ox[c] = o_.x; A.R.oy[c] = o_.y; A.R.oz[c] = o_.z;
-            A.R.dx[c] = refr_dir.x; A.R.dy[c] = refr_dir.y; A.R.dz[c] = refr_dir.z;
+            V3 d_ = normal * refr_a - eye * refr_b;  // world.rs:171
+            A.R.ox()[c] = o_.x; A.R.oy()[c] = o_.y; A.R.oz()[c] = o_.z;
+            A.R.dx()[c] = d_.x; A.R.dy()[c] = d_.y; A.R.dz()[c] = d_.z;
             child_refr = c;
         } else err |= 1u;
     }
     if (on) {
-        A.R.hit_pos[rec_idx] = hit ? hit_pos : NONE;
+        A.R.hit_pos()[rec_idx] = hit ? hit_pos : NONE;
         if (hit) {
-            A.R.px[rec_idx] = over.x; A.R.py[rec_idx] = over.y; A.R.pz[rec_idx] = over.z;
-            A.R.nx[rec_idx] = normal.x; A.R.ny[rec_idx] = normal.y; A.R.nz[rec_idx] = normal.z;
-            A.R.child_refl[rec_idx] = child_refl;
-            A.R.child_refr[rec_idx] = child_refr;
-            if (reflectance >= 0.0) A.R.reflectance[rec_idx] = reflectance;
+            A.R.child_refl()[rec_idx] = child_refl;
+            A.R.child_refr()[rec_idx] = child_refr;
+            if (reflectance >= 0.0) A.R.reflectance()[rec_idx] = reflectance;
+            if constexpr (!LIT) {
+                A.R.px()[rec_idx] = over.x; A.R.py()[rec_idx] = over.y; A.R.pz()[rec_idx] = over.z;
+                A.R.nx()[rec_idx] = normal.x; A.R.ny()[rec_idx] = normal.y; A.R.nz()[rec_idx] = normal.z;
+            }
+        }
+    }
+    const bool has_children = child_refl != NONE || child_refr != NONE || spawn_refl || spawn_refr;
+    PHASE(7);
+
+    // FUSED: the shadow rays of this hit and its surface colour, Σ over lights of Material::lighting
+    // (world.rs:58-70) with pattern_at(object, over_point) (pattern/mod.rs:83-87).  The intensities
+    // wait in the LDS slots the container walk is done with (the first REC_CAP lights; more go
+    // through memory).
+    if constexpr (!PRIMARY && PREFETCH_RAY) {
+        if (step + gridDim.x < n_steps) fetched = fetch_ray(step + gridDim.x);
+    }
+    V3 colour = mk(0.0, 0.0, 0.0);
+    if constexpr (FUSED) {
+        Rng none;
+        none.s0 = none.s1 = none.s2 = none.s3 = 0;
+        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow, 0, NONE,
+                                            LIT ? s_rec_t + threadIdx.x : nullptr);
+        if (LIT && hit) {
+            const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
+            const uint32_t pat_root = (uint32_t)mat_rec[7];
+            PatTables pt;
+            pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+            V3 pat;
+            // a solid root pattern ignores the point (pattern/solid.rs:19): no object-space transform needed
+            if (pt.pat_meta[pat_root * 4] == RT_PAT_SOLID) {
+                pat = mk(pt.pat_col[pat_root * 4 + 0], pt.pat_col[pat_root * 4 + 1], pt.pat_col[pat_root * 4 + 2]);
+            } else {
+                V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
+                pat = pattern_eval(pt, pat_root, object_point);
+            }
+            flops_light += F_PATTERN;
+            V3 surface = mk(0.0, 0.0, 0.0);
+            for (uint32_t l = 0; l < S.n_lights; l++) {
+                const double intensity = l < REC_CAP ? s_rec_t[l * TRACE_BLOCK + threadIdx.x] : A.intensity[(size_t)l * A.rec_cap + rec_idx];
+                surface = surface + lighting_one(S, l, pat, m_ambient, m_diffuse, m_specular, m_shininess, over, normal, eye, intensity, none, flops_light);
+            }
+            // a hit without children is finished here; the others wait for k_fold with their surface colour
+            colour = has_children ? surface
+                                  : combine(surface, mk(0.0, 0.0, 0.0), mk(0.0, 0.0, 0.0), m_reflective, m_transparency, reflectance);
         }
     }
 
-    PHASE(7);
-    n_spawned += (spawn_refl ? 1u : 0u) + (spawn_refr ? 1u : 0u);
-    if (hit) n_shade++;
-    // the shadow rays of this hit, unless the lights need the chunk's rng order first (k_shadow):
-    // their arithmetic fills the issue slots this kernel leaves idle while it waits for memory
-    if constexpr (SHADOWS) {
-        Rng none;
-        none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
+    if constexpr (LIT) {
+        if (on) { A.R.r()[rec_idx] = colour.x; A.R.g()[rec_idx] = colour.y; A.R.b()[rec_idx] = colour.z; }
     }
+    n_spawned += (uint32_t)__popcll(__ballot(spawn_refl)) + (uint32_t)__popcll(__ballot(spawn_refr));
+    n_shade += (uint32_t)__popcll(__ballot(hit));
 #if defined(RT_PHASE_TIMERS) && !defined(RT_PHASE_SHADE)
     {
         __builtin_amdgcn_s_waitcnt(0);
@@ -1655,9 +1883,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
 #endif
     }  // steps
 
-    // statistics: one atomic per wave and counter
-    uint32_t s_shade = wave_sum_u32(n_shade), s_spawned = wave_sum_u32(n_spawned);
-    uint32_t s_flops_lo = wave_sum_u32(flops.flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops.flops >> 16);
+    // statistics: one atomic per wave and counter (the counters are sums over the wave already)
+    const unsigned long long f_trace = flops.flops + wave_sum_u32(flops.lane_flops);
     unsigned long long any_err = __ballot(err != 0);
     if constexpr (PER_LANE) {
         const uint32_t s_nodes = wave_sum_u32(flops.nodes + flops_shadow.nodes), s_tris = wave_sum_u32(flops.tris + flops_shadow.tris);
@@ -1669,17 +1896,18 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     }
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
-        if (s_spawned) atomicAdd(&st->secondary, (unsigned long long)s_spawned);
-        if (s_shade) atomicAdd(&st->shade, (unsigned long long)s_shade);
-        atomicAdd(&st->flop_trace, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
+        if (n_spawned) atomicAdd(&st->secondary, (unsigned long long)n_spawned);
+        if (n_shade) atomicAdd(&st->shade, (unsigned long long)n_shade);
+        atomicAdd(&st->flop_trace, f_trace);
     }
-    if constexpr (SHADOWS) {
-        uint32_t s_shadow = wave_sum_u32(n_shadow);
-        uint32_t sh_lo = wave_sum_u32(flops_shadow.flops & 0xFFFFu), sh_hi = wave_sum_u32(flops_shadow.flops >> 16);
+    if constexpr (FUSED) {
+        const unsigned long long f_shadow = flops_shadow.flops + wave_sum_u32(flops_shadow.lane_flops);
+        uint32_t li_lo = wave_sum_u32(flops_light & 0xFFFFu), li_hi = wave_sum_u32(flops_light >> 16);
         if (lane == 0) {
             StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
-            if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
-            atomicAdd(&st->flop_shadow, (unsigned long long)sh_lo + ((unsigned long long)sh_hi << 16));
+            if (n_shadow) atomicAdd(&st->shadow, (unsigned long long)n_shadow);
+            atomicAdd(&st->flop_shadow, f_shadow);
+            if (li_lo | li_hi) atomicAdd(&st->flop_light, (unsigned long long)li_lo + ((unsigned long long)li_hi << 16));
         }
     }
     if (any_err && err) atomicOr(&A.counters->error, err);
@@ -1706,18 +1934,17 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
         const uint32_t idx = first + threadIdx.x;
         bool on = idx < total;
         const uint32_t rec_idx = on ? idx : 0;
-        const uint32_t hp = A.R.hit_pos[rec_idx];
-        const V3 over = mk(A.R.px[rec_idx], A.R.py[rec_idx], A.R.pz[rec_idx]);  // fetched beside hit_pos, not after it
+        const uint32_t hp = A.R.hit_pos()[rec_idx];
+        const V3 over = mk(A.R.px()[rec_idx], A.R.py()[rec_idx], A.R.pz()[rec_idx]);  // fetched beside hit_pos, not after it
         on = on && hp != NONE;
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-        if (A.rng_states && on) rng = A.rng_states[A.R.order[rec_idx]];
-        const V3 normal = mk(A.R.nx[rec_idx], A.R.ny[rec_idx], A.R.nz[rec_idx]);
+        if (A.rng_states && on) rng = A.rng_states[A.R.order()[rec_idx]];
+        const V3 normal = mk(A.R.nx()[rec_idx], A.R.ny()[rec_idx], A.R.nz()[rec_idx]);
         if (per_light) intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
         else intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
-    uint32_t s_shadow = wave_sum_u32(n_shadow);
-    uint32_t s_flops_lo = wave_sum_u32(flops.flops & 0xFFFFu), s_flops_hi = wave_sum_u32(flops.flops >> 16);
+    const unsigned long long f_shadow = flops.flops + wave_sum_u32(flops.lane_flops);
     unsigned long long any_err = __ballot(err != 0);
     if constexpr (PER_LANE) {
         const uint32_t s_nodes = wave_sum_u32(flops.nodes), s_tris = wave_sum_u32(flops.tris);
@@ -1729,22 +1956,11 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
     }
     if (lane == 0) {
         StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
-        if (s_shadow) atomicAdd(&st->shadow, (unsigned long long)s_shadow);
-        atomicAdd(&st->flop_shadow, (unsigned long long)s_flops_lo + ((unsigned long long)s_flops_hi << 16));
+        if (n_shadow) atomicAdd(&st->shadow, (unsigned long long)n_shadow);
+        atomicAdd(&st->flop_shadow, f_shadow);
     }
     if (any_err && err) atomicOr(&A.counters->error, err);
 }
-
-// Colour::to_u8 (colour.rs:63-72): clamp, * 255, round half away from zero, NaN -> 0.
-DEV uint8_t to_u8(double c) {
-    if (c != c) return 0;
-    double cl = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
-    return (uint8_t)round(cl * 255.0);
-}
-
-// pow() is by far the largest register user of k_shade; out of line it only costs its registers
-// while it runs (155 instead of 168+ VGPRs for the kernel, no spills).
-__device__ __noinline__ double shade_pow(double x, double y) { return pow(x, y); }
 
 // colour_at of every ray of one level, deepest level first: the surface colour, Σ over lights of
 // Material::lighting (world.rs:58-70, material.rs:47-87) with pattern_at(object, over_point)
@@ -1799,10 +2015,10 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
     const uint32_t rec = lv.base + (on ? idx : 0);
     // every column of the record is fetched before the hit test so that the loads overlap
     // (a miss wastes them, but misses are rare and the kernel is bound by load latency)
-    const uint32_t hit_pos = on ? A.R.hit_pos[rec] : NONE;
-    const V3 over = mk(A.R.px[rec], A.R.py[rec], A.R.pz[rec]), normal = mk(A.R.nx[rec], A.R.ny[rec], A.R.nz[rec]);
-    const V3 eye = -mk(A.R.dx[rec], A.R.dy[rec], A.R.dz[rec]);
-    const uint32_t cr_raw = A.R.child_refl[rec], ct_raw = A.R.child_refr[rec];
+    const uint32_t hit_pos = on ? A.R.hit_pos()[rec] : NONE;
+    const V3 over = mk(A.R.px()[rec], A.R.py()[rec], A.R.pz()[rec]), normal = mk(A.R.nx()[rec], A.R.ny()[rec], A.R.nz()[rec]);
+    const V3 eye = -mk(A.R.dx()[rec], A.R.dy()[rec], A.R.dz()[rec]);
+    const uint32_t cr_raw = A.R.child_refl()[rec], ct_raw = A.R.child_refr()[rec];
 #ifdef RT_PHASE_TIMERS
     unsigned long long phase_t[8];
     phase_t[0] = __builtin_readcyclecounter();
@@ -1816,8 +2032,8 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         // the spawned rays' colours are a scattered read from the level below: requested now,
         // needed only after the lighting
         V3 child_r = mk(0.0, 0.0, 0.0), child_t = mk(0.0, 0.0, 0.0);
-        if (cr != NONE) child_r = mk(A.R.r[cr], A.R.g[cr], A.R.b[cr]);
-        if (ct != NONE) child_t = mk(A.R.r[ct], A.R.g[ct], A.R.b[ct]);
+        if (cr != NONE) child_r = mk(A.R.r()[cr], A.R.g()[cr], A.R.b()[cr]);
+        if (ct != NONE) child_t = mk(A.R.r()[ct], A.R.g()[ct], A.R.b()[ct]);
         const double* mat_rec = t_mat + (size_t)t_stream[(size_t)hit_pos * 16 + 1] * 8;
         const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
         const double m_reflective = mat_rec[4], m_transparency = mat_rec[5];
@@ -1834,63 +2050,21 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         PHASE(3);
         Rng rng;
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-        if (A.rng_states) rng = A.rng_states[A.R.order[rec]];
+        if (A.rng_states) rng = A.rng_states[A.R.order()[rec]];
         V3 surface = mk(0.0, 0.0, 0.0);
         flops = F_PATTERN;
         for (uint32_t l = 0; l < S.n_lights; l++) {
-            // wave-uniform light data through the scalar cache
-            const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
-            const uint32_t samples = usteps * vsteps;
-            const bool is_area = clu(S.light_meta, l * 4 + 0) == RT_LIGHT_AREA;
-            const V3 l0 = mk(cld(S.light, l * 12 + 0), cld(S.light, l * 12 + 1), cld(S.light, l * 12 + 2));
-            const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
-            const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
-            const V3 lint = is_area ? mk(cld(S.light, l * 12 + 9), cld(S.light, l * 12 + 10), cld(S.light, l * 12 + 11)) : uc;
             const double intensity = A.intensity[(size_t)l * A.rec_cap + rec];
-            if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
-            V3 col = cmul(pat, lint);
-            V3 ambient = col * m_ambient;
-            V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
-            // With intensity 0 the diffuse and specular sums are multiplied by zero (they are finite
-            // for a non-negative shininess): the loop is skipped, only its rng draws are taken.
-            const bool dark = intensity == 0.0 && m_shininess >= 0.0;
-            if (dark && is_area) rng_skip(rng, 2 * samples);
-            for (uint32_t k = 0; k < (dark ? 0u : samples); k++) {
-                V3 lp = l0;
-                if (is_area) {  // a fresh jitter: positions() is called again (material.rs:64)
-                    double r1 = rng_unit(rng);
-                    V3 p = l0 + uc * ((double)(k % usteps) + r1);
-                    double r2 = rng_unit(rng);
-                    lp = p + vc * ((double)(k / usteps) + r2);
-                }
-                V3 lv = normalise(lp - over);
-                double ldn = dot(lv, normal);
-                if (ldn >= 0.0) {
-                    diffuse = diffuse + (col * m_diffuse) * ldn;
-                    V3 rv = -reflect(lv, normal);
-                    double rde = dot(rv, eye);
-                    if (rde > 0.0) {
-                        double factor = shade_pow(rde, m_shininess);
-                        specular = specular + (lint * m_specular) * factor;
-                    }
-                }
-            }
-            surface = surface + (ambient + ((diffuse + specular) / (double)samples) * intensity);
-            flops += F_LIGHT * samples;
+            surface = surface + lighting_one(S, l, pat, m_ambient, m_diffuse, m_specular, m_shininess, over, normal, eye, intensity, rng, flops);
         }
         PHASE(4);
         // shade_hit's sum (world.rs:72-86); a ray that was not spawned contributes black
         V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
         if (cr != NONE) reflected = child_r * m_reflective;
         if (ct != NONE) refracted = child_t * m_transparency;
-        if (m_reflective > 0.0 && m_transparency > 0.0) {
-            const double Rf = A.R.reflectance[rec];
-            colour = surface + reflected * Rf + refracted * (1.0 - Rf);
-            flops += F_COMBINE + 7;
-        } else {
-            colour = surface + reflected + refracted;
-            flops += F_COMBINE;
-        }
+        const bool both = m_reflective > 0.0 && m_transparency > 0.0;
+        colour = combine(surface, reflected, refracted, m_reflective, m_transparency, both ? A.R.reflectance()[rec] : 0.0);
+        flops += both ? F_COMBINE + 7 : F_COMBINE;
     }
     PHASE(5);
     if (on) {
@@ -1904,7 +2078,7 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
                 o[0] = to_u8(colour.x); o[1] = to_u8(colour.y); o[2] = to_u8(colour.z);
             }
         } else {
-            A.R.r[rec] = colour.x; A.R.g[rec] = colour.y; A.R.b[rec] = colour.z;
+            A.R.r()[rec] = colour.x; A.R.g()[rec] = colour.y; A.R.b()[rec] = colour.z;
         }
     }
     PHASE(6);
@@ -1922,6 +2096,77 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
 }
 
+// The other half of shade_hit for the levels k_trace<FUSED> has shaded (world.rs:72-86): a hit with
+// spawned rays holds its surface colour in the record's colour columns and becomes
+//   surface + reflected * reflectance + refracted * (1 - reflectance)
+// (or the plain sum) once its children's colours are final, deepest level first.  Everything else
+// (misses, hits without children) already holds its final colour.  Level 0 writes the frame.
+// With WEIGHTS_IN_LDS every block first builds a table unit position -> (reflective, transparency)
+// in LDS, so that the hit leaf -> material -> weights chain of dependent loads stays on the CU.
+constexpr uint32_t FOLD_LDS_UNITS = 1024;
+template <bool WEIGHTS_IN_LDS>
+__global__ __launch_bounds__(256) void k_fold(DevScene S, LevelArgs A) {
+    if (A.counters->error & 1u) return;
+    const LevelState lv = A.levels[A.level];
+    __shared__ double s_w[WEIGHTS_IN_LDS ? 2 * FOLD_LDS_UNITS : 1];
+    if constexpr (WEIGHTS_IN_LDS) {
+        for (uint32_t u = threadIdx.x; u < S.n_units; u += 256) {
+            const uint32_t* rec = S.stream + (size_t)u * 16;
+            const bool leaf = (rec[0] & 0xFFu) < K_GROUP && rec[1] < S.n_materials;  // a leaf's second unit holds data, not a header
+            s_w[2 * u] = leaf ? S.mat[(size_t)rec[1] * 8 + 4] : 0.0;
+            s_w[2 * u + 1] = leaf ? S.mat[(size_t)rec[1] * 8 + 5] : 0.0;
+        }
+        __syncthreads();
+    }
+    const bool frame = A.out_rgb || A.out_rgb8;
+    uint32_t flops_sum = 0;
+    for (uint32_t first = blockIdx.x * 256; first < lv.n; first += gridDim.x * 256) {
+        LOOP_FENCE();
+        const uint32_t idx = first + threadIdx.x;
+        const bool on = idx < lv.n;
+        const uint32_t rec = lv.base + (on ? idx : 0);
+        const uint32_t hit_pos = on ? A.R.hit_pos()[rec] : NONE;
+        uint32_t cr = A.R.child_refl()[rec], ct = A.R.child_refr()[rec];  // fetched beside hit_pos; only a hit's are meaningful
+        if (hit_pos == NONE) { cr = NONE; ct = NONE; }
+        const bool fold = cr != NONE || ct != NONE;
+        V3 colour = mk(0.0, 0.0, 0.0);
+        if (fold || (frame && on)) colour = mk(A.R.r()[rec], A.R.g()[rec], A.R.b()[rec]);
+        if (fold) {
+            V3 child_r = mk(0.0, 0.0, 0.0), child_t = mk(0.0, 0.0, 0.0);
+            if (cr != NONE) child_r = mk(A.R.r()[cr], A.R.g()[cr], A.R.b()[cr]);
+            if (ct != NONE) child_t = mk(A.R.r()[ct], A.R.g()[ct], A.R.b()[ct]);
+            double m_reflective, m_transparency;
+            if constexpr (WEIGHTS_IN_LDS) {
+                m_reflective = s_w[2 * hit_pos]; m_transparency = s_w[2 * hit_pos + 1];
+            } else {
+                const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
+                m_reflective = mat_rec[4]; m_transparency = mat_rec[5];
+            }
+            V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
+            if (cr != NONE) reflected = child_r * m_reflective;
+            if (ct != NONE) refracted = child_t * m_transparency;
+            const bool both = m_reflective > 0.0 && m_transparency > 0.0;
+            colour = combine(colour, reflected, refracted, m_reflective, m_transparency, both ? A.R.reflectance()[rec] : 0.0);
+            flops_sum += both ? F_COMBINE + 7 : F_COMBINE;
+        }
+        if (on && frame) {
+            if (A.out_rgb) {
+                double* o = A.out_rgb + (A.out_offset + idx) * 3;
+                o[0] = colour.x; o[1] = colour.y; o[2] = colour.z;
+            }
+            if (A.out_rgb8) {
+                uint8_t* o = A.out_rgb8 + (A.out_offset + idx) * 3;
+                o[0] = to_u8(colour.x); o[1] = to_u8(colour.y); o[2] = to_u8(colour.z);
+            }
+        } else if (fold) {
+            A.R.r()[rec] = colour.x; A.R.g()[rec] = colour.y; A.R.b()[rec] = colour.z;
+        }
+    }
+    uint32_t s_lo = wave_sum_u32(flops_sum & 0xFFFFu), s_hi = wave_sum_u32(flops_sum >> 16);
+    if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
+        atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_fold, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
+}
+
 // Start of a chunk: level 0 holds n0 rays in records [0, n0); everything else is empty.
 __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n0, Counters* counters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1933,15 +2178,15 @@ __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n
 // STAT_SHARDS threads.
 __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* levels, uint32_t n_levels,
                                                            const Counters* counters, StatShard* stats, ChunkStatus* out) {
-    __shared__ unsigned long long sums[8];
-    if (threadIdx.x < 8) sums[threadIdx.x] = 0ull;
+    __shared__ unsigned long long sums[9];
+    if (threadIdx.x < 9) sums[threadIdx.x] = 0ull;
     __syncthreads();
     StatShard* st = stats + threadIdx.x;
     atomicAdd(&sums[0], st->secondary); atomicAdd(&sums[1], st->shadow); atomicAdd(&sums[2], st->shade);
     atomicAdd(&sums[3], st->flop_trace); atomicAdd(&sums[4], st->flop_shadow); atomicAdd(&sums[5], st->flop_light);
-    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris);
+    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris); atomicAdd(&sums[8], st->flop_fold);
     st->secondary = 0; st->shadow = 0; st->shade = 0; st->flop_trace = 0; st->flop_shadow = 0; st->flop_light = 0;
-    st->mesh_nodes = 0; st->mesh_tris = 0;
+    st->mesh_nodes = 0; st->mesh_tris = 0; st->flop_fold = 0;
     __syncthreads();
     if (threadIdx.x != 0) return;
     uint32_t used = 0;
@@ -1953,7 +2198,7 @@ __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* lev
     out->pad = 0;
     out->secondary = sums[0]; out->shadow = sums[1]; out->shade = sums[2];
     out->flop_trace = sums[3]; out->flop_shadow = sums[4]; out->flop_light = sums[5];
-    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7];
+    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7]; out->flop_fold = sums[8];
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
@@ -1965,13 +2210,13 @@ __global__ __launch_bounds__(256) void k_order_sizes(Recs R, uint32_t base, uint
     if (i >= n) return;
     const uint32_t rec = base + i;
     uint32_t s = 0;
-    if (R.hit_pos[rec] != NONE) {
+    if (R.hit_pos()[rec] != NONE) {
         s = 1;
-        const uint32_t cr = R.child_refl[rec], ct = R.child_refr[rec];
-        if (cr != NONE) s += R.order[cr];
-        if (ct != NONE) s += R.order[ct];
+        const uint32_t cr = R.child_refl()[rec], ct = R.child_refr()[rec];
+        if (cr != NONE) s += R.order()[cr];
+        if (ct != NONE) s += R.order()[ct];
     }
-    R.order[rec] = s;
+    R.order()[rec] = s;
 }
 // (2) one block per row: running offsets of the row's pixels; row_total[row] = shade points in the row
 __global__ __launch_bounds__(256) void k_order_rows(Recs R, uint32_t width, uint32_t rows, uint32_t* pixel_base,
@@ -1983,7 +2228,7 @@ __global__ __launch_bounds__(256) void k_order_rows(Recs R, uint32_t width, uint
     const uint32_t per = (width + 255) / 256;
     const uint32_t x0 = min(threadIdx.x * per, width), x1 = min(x0 + per, width);
     uint32_t mine = 0;
-    for (uint32_t x = x0; x < x1; x++) mine += R.order[(size_t)row * width + x];
+    for (uint32_t x = x0; x < x1; x++) mine += R.order()[(size_t)row * width + x];
     s_sum[threadIdx.x] = mine;
     __syncthreads();
     for (uint32_t off = 1; off < 256; off <<= 1) {
@@ -1995,7 +2240,7 @@ __global__ __launch_bounds__(256) void k_order_rows(Recs R, uint32_t width, uint
     uint32_t acc = s_sum[threadIdx.x] - mine;
     for (uint32_t x = x0; x < x1; x++) {
         pixel_base[(size_t)row * width + x] = acc;
-        acc += R.order[(size_t)row * width + x];
+        acc += R.order()[(size_t)row * width + x];
     }
     if (threadIdx.x == 255) row_total[row] = s_sum[255];
 }
@@ -2005,14 +2250,14 @@ __global__ __launch_bounds__(256) void k_order_assign(Recs R, uint32_t base, uin
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t rec = base + i;
-    if (R.hit_pos[rec] == NONE) return;
-    uint32_t mine = R.order[rec];  // level 0: still the subtree size; deeper: already the position
+    if (R.hit_pos()[rec] == NONE) return;
+    uint32_t mine = R.order()[rec];  // level 0: still the subtree size; deeper: already the position
     if (level0) mine = row_base[i / width] + pixel_base[i];
     uint32_t next = mine + 1;
-    const uint32_t cr = R.child_refl[rec], ct = R.child_refr[rec];
-    if (cr != NONE && R.hit_pos[cr] != NONE) { uint32_t sz = R.order[cr]; R.order[cr] = next; next += sz; }
-    if (ct != NONE && R.hit_pos[ct] != NONE) R.order[ct] = next;
-    R.order[rec] = mine;
+    const uint32_t cr = R.child_refl()[rec], ct = R.child_refr()[rec];
+    if (cr != NONE && R.hit_pos()[cr] != NONE) { uint32_t sz = R.order()[cr]; R.order()[cr] = next; next += sz; }
+    if (ct != NONE && R.hit_pos()[ct] != NONE) R.order()[ct] = next;
+    R.order()[rec] = mine;
 }
 // (4) the generator state at every shade point.  Shade point k of a row starts k * draws steps
 // after the row's seed, and the state transition of xoshiro256 is linear over GF(2) (the ++ only
@@ -2086,8 +2331,8 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     bool on = idx < n;
     const uint32_t q = on ? idx : 0;
     Ray ray;
-    ray.o = mk(R.ox[q], R.oy[q], R.oz[q]);
-    ray.d = mk(R.dx[q], R.dy[q], R.dz[q]);
+    ray.o = mk(R.ox()[q], R.oy()[q], R.oz()[q]);
+    ray.d = mk(R.dx()[q], R.dy()[q], R.dz()[q]);
     Work flops{};
     uint32_t err = 0;
     V3 point = mk(0.0, 0.0, 0.0), normal = mk(0.0, 0.0, 0.0);
@@ -2098,8 +2343,8 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     double big_t[CONT_CAP];
     uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
     RecordBuf buf;
-    buf.fast = {s_rec_t + threadIdx.x, s_rec_pos + threadIdx.x, s_rec_cls + threadIdx.x, 256, REC_CAP};
-    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP};
+    buf.fast = {s_rec_t, s_rec_pos, s_rec_cls, 256, REC_CAP, threadIdx.x};
+    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP, 0u};
     Walk w = walk_init();
     bool hit = false, need = false;
     double hit_t = 0.0;
@@ -2141,7 +2386,7 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
                 if (need && !small) {
                     if (w.overflow) err |= 2u;
                     for (int k = 0; k < REC_CAP; k++)
-                        buf.big.put(k, buf.fast.t[k * 256], buf.fast.pos[k * 256], buf.fast.cls[k * 256]);
+                        buf.big.put(k, buf.fast.T(k), buf.fast.P(k), buf.fast.C(k));
                     nn = container_walk_scratch(S.stream, S.mat, big_t, big_pos, big_cls, w.n, hit_t, hit_pos, hit_cls);
                 }
                 if (need) { n1 = nn.n1; n2 = nn.n2; }
@@ -2197,8 +2442,8 @@ __global__ __launch_bounds__(256) void k_load_rays(const double* rays, uint32_t 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double* r = rays + (size_t)i * 6;
-    R.ox[i] = r[0]; R.oy[i] = r[1]; R.oz[i] = r[2];
-    R.dx[i] = r[3]; R.dy[i] = r[4]; R.dz[i] = r[5];
+    R.ox()[i] = r[0]; R.oy()[i] = r[1]; R.oz()[i] = r[2];
+    R.dx()[i] = r[3]; R.dy()[i] = r[4]; R.dz()[i] = r[5];
 }
 // a fill kernel instead of hipMemsetAsync: safe to record into a caller's graph
 __global__ __launch_bounds__(256) void k_zero_words(unsigned long long* p, uint32_t n) {
@@ -2544,13 +2789,7 @@ int ensure_workspace(rt_scene* s, Workspace& w, size_t chunk_px, size_t n_first,
         w.rec_cap = 0;
         const size_t cap = (want_r + 63) & ~(size_t)63;  // every array starts 256-byte aligned
         HIP_TRY(hipMalloc(&w.rec_slab, cap * REC_BYTES));
-        double* d = (double*)w.rec_slab;
-        double** dp[16] = {&w.R.ox, &w.R.oy, &w.R.oz, &w.R.dx, &w.R.dy, &w.R.dz, &w.R.px, &w.R.py,
-                           &w.R.pz, &w.R.nx, &w.R.ny, &w.R.nz, &w.R.reflectance, &w.R.r, &w.R.g, &w.R.b};
-        for (auto pp : dp) { *pp = d; d += cap; }
-        uint32_t* u = (uint32_t*)d;
-        uint32_t** up[4] = {&w.R.hit_pos, &w.R.child_refl, &w.R.child_refr, &w.R.order};
-        for (auto pp : up) { *pp = u; u += cap; }
+        w.R.base = (unsigned char*)w.rec_slab;
         w.rec_cap = cap;
     }
     if (w.rec_cap * s->dev.n_lights > w.intensity_cap || (size_t)depth + 2 > w.levels_cap || n_chunks > w.status_cap)
@@ -2578,7 +2817,7 @@ void free_workspace(Workspace& w) {
 }
 
 struct RunTotals {
-    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0, mesh_nodes = 0, mesh_tris = 0;
+    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0, mesh_nodes = 0, mesh_tris = 0, flop_fold = 0;
     uint64_t trace_launches = 0;
     uint32_t levels = 0;
     double ms_trace = 0, ms_shadow = 0, ms_shade = 0;
@@ -2716,10 +2955,15 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     }
     if (!shadows_queued && !fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
+    const bool fused = FUSE_LIGHTING && fused_shadows(s, PER_LANE);  // k_trace has shaded: only the sums with the children's colours are left
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
         if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
-        if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
+        if (fused) {
+            if (level == (int)n_levels - 1 && level != 0) continue;  // the deepest level spawns nothing
+            if (s->dev.n_units <= FOLD_LDS_UNITS) hipLaunchKernelGGL(k_fold<true>, grid, block, 0, st, s->dev, A);
+            else hipLaunchKernelGGL(k_fold<false>, grid, block, 0, st, s->dev, A);
+        } else if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
         else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, st, s->dev, A);
     }
     if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
@@ -2762,7 +3006,7 @@ int collect(Workspace& w, size_t n_slots, std::vector<ChunkStatus>& out, RunTota
 void add_stats(RunTotals& tot, const ChunkStatus& c) {
     tot.secondary += c.secondary; tot.shadow += c.shadow; tot.shade += c.shade;
     tot.flop_trace += c.flop_trace; tot.flop_shadow += c.flop_shadow; tot.flop_light += c.flop_light;
-    tot.mesh_nodes += c.mesh_nodes; tot.mesh_tris += c.mesh_tris;
+    tot.mesh_nodes += c.mesh_nodes; tot.mesh_tris += c.mesh_tris; tot.flop_fold += c.flop_fold;
     tot.levels = std::max(tot.levels, c.levels);
 }
 
@@ -2782,7 +3026,7 @@ void print_phases(Workspace& w) {
     (void)hipMemset(w.stats, 0, STAT_SHARDS * sizeof(StatShard));
     unsigned long long ph[8] = {0};
     for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
-    static const char* names[8] = {"shadows", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
+    static const char* names[8] = {"(step end)", "ray", "walk", "material", "containers", "geometry", "spawn+post", "shading+pickup+stores"};
     for (int k = 0; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
 }
 #endif
@@ -2805,12 +3049,16 @@ int upload_seeds(rt_scene* s, const uint64_t* seeds, size_t n) {
 }
 
 int upload_rays(Workspace& w, uint32_t n, const double* rays) {
-    double* dst[6] = {w.R.ox, w.R.oy, w.R.oz, w.R.dx, w.R.dy, w.R.dz};
-    std::vector<double> host(n);
-    for (int c = 0; c < 6; c++) {
-        for (uint32_t i = 0; i < n; i++) host[i] = rays[6 * (size_t)i + c];
-        HIP_TRY(hipMemcpy(dst[c], host.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    double* staged = nullptr;
+    HIP_TRY(hipMalloc((void**)&staged, (size_t)n * 6 * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(staged, rays, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, w.stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, w.stream, staged, n, w.R);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
+    (void)hipFree(staged);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
     return RT_OK;
 }
 
@@ -2842,6 +3090,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             if (d->node_arg[i] != leaf_seen++) return fail(RT_ERR_INVALID, "leaves must be numbered in node order");
         } else if (d->node_kind[i] == RT_NODE_CSG) {
             if (d->node_arg[i] != csg_seen++) return fail(RT_ERR_INVALID, "csgs must be numbered in node order");
+            if (d->node_arg[i] < d->n_csgs && d->csg_op[d->node_arg[i]] > RT_CSG_UNION) return fail(RT_ERR_INVALID, "unknown csg operation");
             if (i + 1 >= d->n_nodes || d->node_skip[i + 1] >= d->node_skip[i])
                 return fail(RT_ERR_INVALID, "a csg needs a left and a right subtree");
             if (d->node_skip[d->node_skip[i + 1]] != d->node_skip[i])
@@ -2884,21 +3133,63 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
         }
     }
 
+    if (draws > 0xFFFFFFFFull) return fail(RT_ERR_INVALID, "the area lights take more than 2^32 rng draws per shade point");
+    // ---- enclosing node of every node, and whether it lies inside a csg
+    std::vector<uint32_t> parent_node(d->n_nodes, NONE);
+    std::vector<uint8_t> in_csg(d->n_nodes, 0);
+    {
+        std::vector<uint32_t> open;
+        uint32_t open_csgs = 0;
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            while (!open.empty() && d->node_skip[open.back()] <= i) {
+                if (d->node_kind[open.back()] == RT_NODE_CSG) open_csgs--;
+                open.pop_back();
+            }
+            parent_node[i] = open.empty() ? NONE : open.back();
+            if (!open.empty() && d->node_skip[i] > d->node_skip[open.back()])
+                return fail(RT_ERR_INVALID, "a node's subtree must end inside its parent's");
+            in_csg[i] = open_csgs > 0;
+            if (d->node_kind[i] != RT_NODE_LEAF) {
+                open.push_back(i);
+                if (d->node_kind[i] == RT_NODE_CSG) open_csgs++;
+            }
+        }
+    }
+    // ---- bounding spheres of the bounded leaves, and the clusters: runs of three or more sibling
+    // leaves with bounding spheres, outside any csg, get a header unit of their own (see K_CLUSTER)
+    std::vector<double> leaf_sphere((size_t)d->n_nodes * 6, 0.0);
+    std::vector<uint8_t> has_sphere(d->n_nodes, 0);
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        if (d->node_kind[i] != RT_NODE_LEAF) continue;
+        const uint32_t leaf = d->node_arg[i];
+        has_sphere[i] = bounding_sphere(d->leaf_shape[leaf], d->leaf_inv + (size_t)leaf * 12, d->leaf_param[(size_t)leaf * 3 + 0],
+                                        d->leaf_param[(size_t)leaf * 3 + 1], &leaf_sphere[(size_t)i * 6]);
+    }
+#ifndef CLUSTER_MIN_LEAVES
+#define CLUSTER_MIN_LEAVES 3
+#endif
+    constexpr uint32_t CLUSTER_MIN = CLUSTER_MIN_LEAVES;
+    std::vector<uint32_t> cluster_end(d->n_nodes, 0);  // at the first node of a run: the node after it
+    for (uint32_t i = 0; i < d->n_nodes;) {
+        uint32_t j = i;
+        while (j < d->n_nodes && d->node_kind[j] == RT_NODE_LEAF && has_sphere[j] && !in_csg[j] && parent_node[j] == parent_node[i]) j++;
+        if (j - i >= CLUSTER_MIN) cluster_end[i] = j;
+        i = std::max(j, i + 1);
+    }
+
     // ---- node stream
     std::vector<uint32_t> unit_of(d->n_nodes + 1);
     uint32_t units = 0;
     for (uint32_t i = 0; i < d->n_nodes; i++) {
+        if (cluster_end[i]) units += 1;  // the cluster's header comes right before its first leaf
         unit_of[i] = units;
         units += d->node_kind[i] == RT_NODE_LEAF ? 2 : 1;
     }
     unit_of[d->n_nodes] = units;
+    // where a subtree that ends at node k ends in the stream: a cluster header belongs to the run behind it
+    auto end_unit = [&](uint32_t k) { return k < d->n_nodes && cluster_end[k] ? unit_of[k] - 1 : unit_of[k]; };
     std::vector<uint32_t> stream((size_t)(units + 4) * 16, 0);  // padded: the walk may read one record ahead
     std::vector<double> xforms, tri_normals((size_t)d->n_tris * 9, 0.0), cull((size_t)(units + 4) * 6, 0.0);
-    auto inside_csg = [&](uint32_t node) {
-        for (uint32_t j = 0; j < node; j++)
-            if (d->node_kind[j] == RT_NODE_CSG && d->node_skip[j] > node) return true;
-        return false;
-    };
     std::map<std::vector<uint64_t>, uint32_t> xform_ids;
     bool has_csg = false;
     for (uint32_t i = 0; i < d->n_nodes; i++) {
@@ -2932,7 +3223,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 for (int k = 0; k < 12; k++) recd[2 + k] = inv[k];
                 recd[14] = d->leaf_param[(size_t)leaf * 3 + 0];
                 recd[15] = d->leaf_param[(size_t)leaf * 3 + 1];
-                if (bounding_sphere(shape, inv, recd[14], recd[15], &cull[(size_t)unit_of[i] * 6])) {
+                if (has_sphere[i]) {
+                    std::memcpy(&cull[(size_t)unit_of[i] * 6], &leaf_sphere[(size_t)i * 6], 6 * sizeof(double));
                     rec[0] |= 1u << 10;
                     // Wholly behind the origin a leaf only has intersections with t < 0.  A walk that
                     // records wants those too, unless they cancel: a sphere or cube outside any csg is
@@ -2940,19 +3232,49 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                     // that only wants the closest hit can skip the leaf (bit 16) - but inside a csg only
                     // if it is entered and left: an open cylinder or a cone can be crossed once, which
                     // flips the csg's inside state for everything in front of the origin.
-                    const bool in_csg = inside_csg(i), pairs = shape == RT_SPHERE || shape == RT_CUBE;
-                    if (pairs && !in_csg) rec[0] |= 1u << 11;
-                    if (pairs || !in_csg) rec[0] |= 1u << 16;
+                    const bool pairs = shape == RT_SPHERE || shape == RT_CUBE;
+                    if (pairs && !in_csg[i]) rec[0] |= 1u << 11;
+                    if (pairs || !in_csg[i]) rec[0] |= 1u << 16;
                 }
             }
         } else {
             bool csg = d->node_kind[i] == RT_NODE_CSG;
             has_csg |= csg;
             rec[0] = csg ? K_CSG : K_GROUP;
-            rec[1] = unit_of[d->node_skip[i]];
+            rec[1] = end_unit(d->node_skip[i]);
             rec[2] = csg ? d->node_arg[i] : 0;
             for (int k = 0; k < 6; k++) recd[2 + k] = d->node_bbox[(size_t)i * 6 + k];
         }
+    }
+
+    // cluster headers: a sphere around the members' bounding spheres, the algorithmic cost of the
+    // members' tests, and the members' common "may be skipped when wholly behind the origin" bits
+    for (uint32_t i = 0; i < d->n_nodes; i++) {
+        if (!cluster_end[i]) continue;
+        const uint32_t n = cluster_end[i] - i;
+        double c[3] = {0.0, 0.0, 0.0};
+        for (uint32_t j = i; j < cluster_end[i]; j++)
+            for (int a = 0; a < 3; a++) c[a] += leaf_sphere[(size_t)j * 6 + a] / (double)n;
+        double radius = 0.0;
+        uint32_t bits = (1u << 11) | (1u << 16), cost = 0;
+        for (uint32_t j = i; j < cluster_end[i]; j++) {
+            const double* ls = &leaf_sphere[(size_t)j * 6];
+            const double dx = ls[0] - c[0], dy = ls[1] - c[1], dz = ls[2] - c[2];
+            radius = std::max(radius, std::sqrt(dx * dx + dy * dy + dz * dz) + ls[3]);
+            bits &= stream[(size_t)unit_of[j] * 16];
+            const uint32_t shape = d->leaf_shape[d->node_arg[j]];
+            cost += F_XFORM + (shape == RT_SPHERE ? F_SPHERE : shape == RT_CUBE ? F_BOX : shape == RT_CYLINDER ? F_CYL : F_CONE);
+        }
+        radius = radius * (1.0 + 1e-9) + 1e-9;
+        uint32_t* rec = &stream[(size_t)(unit_of[i] - 1) * 16];
+        double* cs = &cull[(size_t)(unit_of[i] - 1) * 6];
+        const bool ok = std::isfinite(radius) && std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]);
+        rec[0] = K_CLUSTER | (ok ? bits : 0u);
+        rec[1] = end_unit(cluster_end[i]);
+        rec[2] = cost;
+        // a header that must never cull: a sphere nothing is outside of
+        cs[0] = ok ? c[0] : 0.0; cs[1] = ok ? c[1] : 0.0; cs[2] = ok ? c[2] : 0.0;
+        cs[3] = ok ? radius : HUGE_VAL; cs[4] = ok ? radius * radius : HUGE_VAL;
     }
 
     // groups whose stored box certainly holds their subtree: all six coordinates finite and no
@@ -2982,16 +3304,11 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     MeshBuild meshes;
     meshes.stream = stream.data();
     {
-        std::vector<uint32_t> parent_node(d->n_nodes, NONE), open;
-        for (uint32_t i = 0; i < d->n_nodes; i++) {
-            while (!open.empty() && d->node_skip[open.back()] <= i) open.pop_back();
-            parent_node[i] = open.empty() ? NONE : open.back();
-            if (d->node_kind[i] != RT_NODE_LEAF) open.push_back(i);
-        }
         for (uint32_t i = 0; i < d->n_nodes; i++) {
             uint32_t pu = parent_node[i] == NONE ? NONE : unit_of[parent_node[i]];
             parent_unit[unit_of[i]] = pu;
             if (d->node_kind[i] == RT_NODE_LEAF) parent_unit[unit_of[i] + 1] = pu;
+            if (cluster_end[i]) parent_unit[unit_of[i] - 1] = pu;
         }
         constexpr uint32_t MIXED = 0xFFFFFFFEu;           // more than one matrix, or something that is no triangle
         std::vector<uint32_t> matrix(d->n_nodes, NONE);   // NONE: nothing below yet
@@ -3015,7 +3332,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
             if (d->node_kind[i] != RT_NODE_GROUP || matrix[i] == NONE || matrix[i] == MIXED) continue;
             if (parent_node[i] != NONE && matrix[parent_node[i]] != MIXED) continue;   // part of a larger mesh
             if (n_below[i] < MESH_MIN_TRIS || n_below[i] >= (1u << 27) || levels[i] >= (uint32_t)BVH_STACK - 2) continue;
-            if (inside_csg(i)) continue;
+            if (in_csg[i]) continue;
             std::vector<MeshTri> tris;
             tris.reserve(n_below[i]);
             bool finite = true;
@@ -3338,6 +3655,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->flop_light = tot.flop_light;
         stats->mesh_nodes = tot.mesh_nodes;
         stats->mesh_tris = tot.mesh_tris;
+        stats->flop_fold = tot.flop_fold;
         stats->fused_shadows = fused_shadows(s, uses_lane_walk(s)) ? 1 : 0;
     }
     return RT_OK;
@@ -3416,14 +3734,10 @@ int rt_colour_at_noalloc(rt_scene* s, uint32_t n, const double* rays_dev, uint32
     w.status = (ChunkStatus*)take(sizeof(ChunkStatus));
     w.levels = (LevelState*)take(((size_t)RT_NOALLOC_MAX_DEPTH + 2) * sizeof(LevelState));
     const size_t per_rec = REC_BYTES + 8 * (size_t)s->dev.n_lights;
-    const size_t cap = ((SCRATCH_BYTES - off) / per_rec) & ~(size_t)63;  // 64 records = 512 bytes of a f64 column
+    const size_t cap = ((SCRATCH_BYTES - off - 1024) / per_rec) & ~(size_t)63;  // 64 records = 512 bytes of a f64 column; room for the rounding in take()
     if (cap < n) return fail(RT_ERR_CAPACITY, "the static scratch cannot hold one record per ray for this scene's lights");
-    double** dp[16] = {&w.R.ox, &w.R.oy, &w.R.oz, &w.R.dx, &w.R.dy, &w.R.dz, &w.R.px, &w.R.py,
-                       &w.R.pz, &w.R.nx, &w.R.ny, &w.R.nz, &w.R.reflectance, &w.R.r, &w.R.g, &w.R.b};
-    for (auto pp : dp) *pp = (double*)take(cap * sizeof(double));
+    w.R.base = take(cap * REC_BYTES);
     w.intensity = (double*)take(cap * s->dev.n_lights * sizeof(double));
-    uint32_t** up[4] = {&w.R.hit_pos, &w.R.child_refl, &w.R.child_refr, &w.R.order};
-    for (auto pp : up) *pp = (uint32_t*)take(cap * sizeof(uint32_t));
     if (off > SCRATCH_BYTES) return fail(RT_ERR_CAPACITY, "static scratch layout overflow");
     w.rec_cap = cap;
 
