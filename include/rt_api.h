@@ -164,9 +164,6 @@ typedef struct rt_stats {
     uint64_t mesh_nodes;     /* nodes of the meshes' own hierarchies visited (128 bytes
                                 fetched each) and triangles tested in their leaves  */
     uint64_t mesh_tris;      /* (80 bytes each), by all rays of the frame           */
-    uint64_t flop_fold;      /* with fused_shadows k_trace also computes the lighting
-                                (flop_light then belongs to it) and k_fold only adds
-                                the spawned rays' colours: these are its FLOP       */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;

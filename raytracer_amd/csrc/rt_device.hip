@@ -84,9 +84,6 @@ constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one st
 #ifndef PREFETCH_RAY
 #define PREFETCH_RAY 1    // k_trace fetches the next step's ray before this step's shadow walk
 #endif
-#ifndef FUSE_LIGHTING
-#define FUSE_LIGHTING 0   // 1: k_trace of scenes without an area light also computes Material::lighting and k_fold only adds the children (measured slower: the lighting does not fit k_trace's registers)
-#endif
 #ifndef REC_CAP
 #define REC_CAP 8         // candidates per lane recorded in LDS during the closest-hit walk (16 B each)
 #endif
@@ -1150,13 +1147,13 @@ struct Counters {
 struct LevelState { uint32_t n, base; };
 struct ChunkStatus {
     uint32_t error, total_recs, levels, pad;
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris, flop_fold;  // this chunk's statistics
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;  // this chunk's statistics
 };
 // Statistics are spread over STAT_SHARDS cache lines (by block index): every wave adds to them once,
 // and atomics to a single line serialise at ~85 wave-operations per microsecond on this chip.
 constexpr uint32_t STAT_SHARDS = 256;
 struct __attribute__((aligned(64))) StatShard {
-    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris, flop_fold;
+    unsigned long long secondary, shadow, shade, flop_trace, flop_shadow, flop_light, mesh_nodes, mesh_tris;
 #ifdef RT_PHASE_TIMERS
     unsigned long long phase[8];  // shader-clock ticks per k_trace phase, summed over waves
 #endif
@@ -1489,8 +1486,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
-                     Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE,
-                     double* lds_out = nullptr) {
+                     Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE) {
     if (__ballot(on) == 0ull) return;
     l_end = min(l_end, S.n_lights);  // a wave-uniform range of lights (all of them unless told otherwise)
     for (uint32_t l = l_begin; l < l_end; l++) {
@@ -1540,9 +1536,7 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
         }
         if (on) {
             double intensity = is_area ? unshadowed / (double)samples : (unshadowed != 0.0 ? 1.0 : 0.0);
-            // k_trace keeps the first lights' values in its block's LDS (entry l of this lane at l * TRACE_BLOCK)
-            if (lds_out && l < REC_CAP) lds_out[l * TRACE_BLOCK] = intensity;
-            else A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
+            A.intensity[(size_t)l * A.rec_cap + rec_idx] = intensity;
         }
         if (is_area) rng_skip(rng, 2 * samples);  // lighting's own draws for this light
     }
@@ -1614,10 +1608,11 @@ DEV V3 combine(V3 surface, V3 reflected, V3 refracted, double m_reflective, doub
     return surface + reflected + refracted;
 }
 
-// colour_at for every ray of one level, minus the recursion (world.rs:33-49,129-177;
-// intersection/mod.rs:45-109).  With FUSED the kernel also casts the hit's shadow rays and computes
-// its surface colour (Material::lighting), so that only the sum with the spawned rays' colours is
-// left for k_fold; otherwise it stores the hit's geometry for k_shadow and k_shade.
+// colour_at for every ray of one level, minus the shading and the recursion (world.rs:33-49,129-177;
+// intersection/mod.rs:45-109).  With FUSED the kernel also casts the hit's shadow rays (their
+// arithmetic fills the issue slots this kernel leaves idle while it waits for memory); otherwise
+// k_shadow does.  Computing Material::lighting here as well was measured: the kernel then no longer
+// fits its 128 registers without spills and loses more than k_shade saves.
 // Without CULL every walk is the reference's, test for test (a slow mode the others are checked against).
 //
 // The rays a block spawns in one step are appended to the next level together: one atomic on the
@@ -1630,7 +1625,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
     constexpr uint32_t WAVES = TRACE_BLOCK / 64;
-    constexpr bool LIT = FUSED && FUSE_LIGHTING;  // the surface colour is computed here
     __shared__ double s_rec_t[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_rec_pos[REC_CAP * TRACE_BLOCK], s_rec_cls[REC_CAP * TRACE_BLOCK];
     __shared__ uint32_t s_hist[2][SPAWN_BINS], s_off[2][SPAWN_BINS];
@@ -1651,7 +1645,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP, 0u};
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     Work flops{}, flops_shadow{};
-    uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0, flops_light = 0;
+    uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0;
     // one step = TRACE_BLOCK rays (primary: TRACE_BLOCK / 64 tiles of 8x8 pixels)
     // A lane-walked level with few rays spreads them over more waves (`lanes` active lanes in each, a
     // power of two): lanes of one wave at different kinds of node take turns, so a wave's walk costs
@@ -1703,7 +1697,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
         ray = ray_for_pixel(A, on ? x : 0, gy);
         flops.add(F_PRIMARY, on);
         if (on) {
-            if constexpr (!LIT) { A.R.dx()[rec_idx] = ray.d.x; A.R.dy()[rec_idx] = ray.d.y; A.R.dz()[rec_idx] = ray.d.z; }
+            A.R.dx()[rec_idx] = ray.d.x; A.R.dy()[rec_idx] = ray.d.y; A.R.dz()[rec_idx] = ray.d.z;
         }
     } else {
         uint32_t idx = step * rays_per_step + wave_in_block * lanes + lane;
@@ -1819,55 +1813,20 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
             A.R.child_refl()[rec_idx] = child_refl;
             A.R.child_refr()[rec_idx] = child_refr;
             if (reflectance >= 0.0) A.R.reflectance()[rec_idx] = reflectance;
-            if constexpr (!LIT) {
-                A.R.px()[rec_idx] = over.x; A.R.py()[rec_idx] = over.y; A.R.pz()[rec_idx] = over.z;
-                A.R.nx()[rec_idx] = normal.x; A.R.ny()[rec_idx] = normal.y; A.R.nz()[rec_idx] = normal.z;
-            }
+            A.R.px()[rec_idx] = over.x; A.R.py()[rec_idx] = over.y; A.R.pz()[rec_idx] = over.z;
+            A.R.nx()[rec_idx] = normal.x; A.R.ny()[rec_idx] = normal.y; A.R.nz()[rec_idx] = normal.z;
         }
     }
-    const bool has_children = child_refl != NONE || child_refr != NONE || spawn_refl || spawn_refr;
     PHASE(7);
 
-    // FUSED: the shadow rays of this hit and its surface colour, Σ over lights of Material::lighting
-    // (world.rs:58-70) with pattern_at(object, over_point) (pattern/mod.rs:83-87).  The intensities
-    // wait in the LDS slots the container walk is done with (the first REC_CAP lights; more go
-    // through memory).
     if constexpr (!PRIMARY && PREFETCH_RAY) {
         if (step + gridDim.x < n_steps) fetched = fetch_ray(step + gridDim.x);
     }
-    V3 colour = mk(0.0, 0.0, 0.0);
+    // the shadow rays of this hit, unless the lights need the chunk's rng order first (k_shadow)
     if constexpr (FUSED) {
         Rng none;
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow, 0, NONE,
-                                            LIT ? s_rec_t + threadIdx.x : nullptr);
-        if (LIT && hit) {
-            const double m_ambient = mat_rec[0], m_diffuse = mat_rec[1], m_specular = mat_rec[2], m_shininess = mat_rec[3];
-            const uint32_t pat_root = (uint32_t)mat_rec[7];
-            PatTables pt;
-            pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
-            V3 pat;
-            // a solid root pattern ignores the point (pattern/solid.rs:19): no object-space transform needed
-            if (pt.pat_meta[pat_root * 4] == RT_PAT_SOLID) {
-                pat = mk(pt.pat_col[pat_root * 4 + 0], pt.pat_col[pat_root * 4 + 1], pt.pat_col[pat_root * 4 + 2]);
-            } else {
-                V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, hit_pos), over);
-                pat = pattern_eval(pt, pat_root, object_point);
-            }
-            flops_light += F_PATTERN;
-            V3 surface = mk(0.0, 0.0, 0.0);
-            for (uint32_t l = 0; l < S.n_lights; l++) {
-                const double intensity = l < REC_CAP ? s_rec_t[l * TRACE_BLOCK + threadIdx.x] : A.intensity[(size_t)l * A.rec_cap + rec_idx];
-                surface = surface + lighting_one(S, l, pat, m_ambient, m_diffuse, m_specular, m_shininess, over, normal, eye, intensity, none, flops_light);
-            }
-            // a hit without children is finished here; the others wait for k_fold with their surface colour
-            colour = has_children ? surface
-                                  : combine(surface, mk(0.0, 0.0, 0.0), mk(0.0, 0.0, 0.0), m_reflective, m_transparency, reflectance);
-        }
-    }
-
-    if constexpr (LIT) {
-        if (on) { A.R.r()[rec_idx] = colour.x; A.R.g()[rec_idx] = colour.y; A.R.b()[rec_idx] = colour.z; }
+        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
     }
     n_spawned += (uint32_t)__popcll(__ballot(spawn_refl)) + (uint32_t)__popcll(__ballot(spawn_refr));
     n_shade += (uint32_t)__popcll(__ballot(hit));
@@ -1902,12 +1861,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     }
     if constexpr (FUSED) {
         const unsigned long long f_shadow = flops_shadow.flops + wave_sum_u32(flops_shadow.lane_flops);
-        uint32_t li_lo = wave_sum_u32(flops_light & 0xFFFFu), li_hi = wave_sum_u32(flops_light >> 16);
         if (lane == 0) {
             StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
             if (n_shadow) atomicAdd(&st->shadow, (unsigned long long)n_shadow);
             atomicAdd(&st->flop_shadow, f_shadow);
-            if (li_lo | li_hi) atomicAdd(&st->flop_light, (unsigned long long)li_lo + ((unsigned long long)li_hi << 16));
         }
     }
     if (any_err && err) atomicOr(&A.counters->error, err);
@@ -2096,77 +2053,6 @@ __global__ __launch_bounds__(256, SHADE_WAVES) void k_shade(DevScene S, LevelArg
         atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_light, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
 }
 
-// The other half of shade_hit for the levels k_trace<FUSED> has shaded (world.rs:72-86): a hit with
-// spawned rays holds its surface colour in the record's colour columns and becomes
-//   surface + reflected * reflectance + refracted * (1 - reflectance)
-// (or the plain sum) once its children's colours are final, deepest level first.  Everything else
-// (misses, hits without children) already holds its final colour.  Level 0 writes the frame.
-// With WEIGHTS_IN_LDS every block first builds a table unit position -> (reflective, transparency)
-// in LDS, so that the hit leaf -> material -> weights chain of dependent loads stays on the CU.
-constexpr uint32_t FOLD_LDS_UNITS = 1024;
-template <bool WEIGHTS_IN_LDS>
-__global__ __launch_bounds__(256) void k_fold(DevScene S, LevelArgs A) {
-    if (A.counters->error & 1u) return;
-    const LevelState lv = A.levels[A.level];
-    __shared__ double s_w[WEIGHTS_IN_LDS ? 2 * FOLD_LDS_UNITS : 1];
-    if constexpr (WEIGHTS_IN_LDS) {
-        for (uint32_t u = threadIdx.x; u < S.n_units; u += 256) {
-            const uint32_t* rec = S.stream + (size_t)u * 16;
-            const bool leaf = (rec[0] & 0xFFu) < K_GROUP && rec[1] < S.n_materials;  // a leaf's second unit holds data, not a header
-            s_w[2 * u] = leaf ? S.mat[(size_t)rec[1] * 8 + 4] : 0.0;
-            s_w[2 * u + 1] = leaf ? S.mat[(size_t)rec[1] * 8 + 5] : 0.0;
-        }
-        __syncthreads();
-    }
-    const bool frame = A.out_rgb || A.out_rgb8;
-    uint32_t flops_sum = 0;
-    for (uint32_t first = blockIdx.x * 256; first < lv.n; first += gridDim.x * 256) {
-        LOOP_FENCE();
-        const uint32_t idx = first + threadIdx.x;
-        const bool on = idx < lv.n;
-        const uint32_t rec = lv.base + (on ? idx : 0);
-        const uint32_t hit_pos = on ? A.R.hit_pos()[rec] : NONE;
-        uint32_t cr = A.R.child_refl()[rec], ct = A.R.child_refr()[rec];  // fetched beside hit_pos; only a hit's are meaningful
-        if (hit_pos == NONE) { cr = NONE; ct = NONE; }
-        const bool fold = cr != NONE || ct != NONE;
-        V3 colour = mk(0.0, 0.0, 0.0);
-        if (fold || (frame && on)) colour = mk(A.R.r()[rec], A.R.g()[rec], A.R.b()[rec]);
-        if (fold) {
-            V3 child_r = mk(0.0, 0.0, 0.0), child_t = mk(0.0, 0.0, 0.0);
-            if (cr != NONE) child_r = mk(A.R.r()[cr], A.R.g()[cr], A.R.b()[cr]);
-            if (ct != NONE) child_t = mk(A.R.r()[ct], A.R.g()[ct], A.R.b()[ct]);
-            double m_reflective, m_transparency;
-            if constexpr (WEIGHTS_IN_LDS) {
-                m_reflective = s_w[2 * hit_pos]; m_transparency = s_w[2 * hit_pos + 1];
-            } else {
-                const double* mat_rec = S.mat + (size_t)S.stream[(size_t)hit_pos * 16 + 1] * 8;
-                m_reflective = mat_rec[4]; m_transparency = mat_rec[5];
-            }
-            V3 reflected = mk(0.0, 0.0, 0.0), refracted = mk(0.0, 0.0, 0.0);
-            if (cr != NONE) reflected = child_r * m_reflective;
-            if (ct != NONE) refracted = child_t * m_transparency;
-            const bool both = m_reflective > 0.0 && m_transparency > 0.0;
-            colour = combine(colour, reflected, refracted, m_reflective, m_transparency, both ? A.R.reflectance()[rec] : 0.0);
-            flops_sum += both ? F_COMBINE + 7 : F_COMBINE;
-        }
-        if (on && frame) {
-            if (A.out_rgb) {
-                double* o = A.out_rgb + (A.out_offset + idx) * 3;
-                o[0] = colour.x; o[1] = colour.y; o[2] = colour.z;
-            }
-            if (A.out_rgb8) {
-                uint8_t* o = A.out_rgb8 + (A.out_offset + idx) * 3;
-                o[0] = to_u8(colour.x); o[1] = to_u8(colour.y); o[2] = to_u8(colour.z);
-            }
-        } else if (fold) {
-            A.R.r()[rec] = colour.x; A.R.g()[rec] = colour.y; A.R.b()[rec] = colour.z;
-        }
-    }
-    uint32_t s_lo = wave_sum_u32(flops_sum & 0xFFFFu), s_hi = wave_sum_u32(flops_sum >> 16);
-    if ((threadIdx.x & 63) == 0 && (s_lo | s_hi))
-        atomicAdd(&A.stats[blockIdx.x % STAT_SHARDS].flop_fold, (unsigned long long)s_lo + ((unsigned long long)s_hi << 16));
-}
-
 // Start of a chunk: level 0 holds n0 rays in records [0, n0); everything else is empty.
 __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n0, Counters* counters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2178,15 +2064,15 @@ __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n
 // STAT_SHARDS threads.
 __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* levels, uint32_t n_levels,
                                                            const Counters* counters, StatShard* stats, ChunkStatus* out) {
-    __shared__ unsigned long long sums[9];
-    if (threadIdx.x < 9) sums[threadIdx.x] = 0ull;
+    __shared__ unsigned long long sums[8];
+    if (threadIdx.x < 8) sums[threadIdx.x] = 0ull;
     __syncthreads();
     StatShard* st = stats + threadIdx.x;
     atomicAdd(&sums[0], st->secondary); atomicAdd(&sums[1], st->shadow); atomicAdd(&sums[2], st->shade);
     atomicAdd(&sums[3], st->flop_trace); atomicAdd(&sums[4], st->flop_shadow); atomicAdd(&sums[5], st->flop_light);
-    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris); atomicAdd(&sums[8], st->flop_fold);
+    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris);
     st->secondary = 0; st->shadow = 0; st->shade = 0; st->flop_trace = 0; st->flop_shadow = 0; st->flop_light = 0;
-    st->mesh_nodes = 0; st->mesh_tris = 0; st->flop_fold = 0;
+    st->mesh_nodes = 0; st->mesh_tris = 0;
     __syncthreads();
     if (threadIdx.x != 0) return;
     uint32_t used = 0;
@@ -2198,7 +2084,7 @@ __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* lev
     out->pad = 0;
     out->secondary = sums[0]; out->shadow = sums[1]; out->shade = sums[2];
     out->flop_trace = sums[3]; out->flop_shadow = sums[4]; out->flop_light = sums[5];
-    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7]; out->flop_fold = sums[8];
+    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7];
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
@@ -2817,7 +2703,7 @@ void free_workspace(Workspace& w) {
 }
 
 struct RunTotals {
-    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0, mesh_nodes = 0, mesh_tris = 0, flop_fold = 0;
+    uint64_t secondary = 0, shadow = 0, shade = 0, flop_trace = 0, flop_shadow = 0, flop_light = 0, mesh_nodes = 0, mesh_tris = 0;
     uint64_t trace_launches = 0;
     uint32_t levels = 0;
     double ms_trace = 0, ms_shadow = 0, ms_shade = 0;
@@ -2955,15 +2841,10 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     }
     if (!shadows_queued && !fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
     if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
-    const bool fused = FUSE_LIGHTING && fused_shadows(s, PER_LANE);  // k_trace has shaded: only the sums with the children's colours are left
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
         if (level == 0) { A.out_rgb = out_rgb; A.out_rgb8 = out_rgb8; A.out_offset = out_offset; }
-        if (fused) {
-            if (level == (int)n_levels - 1 && level != 0) continue;  // the deepest level spawns nothing
-            if (s->dev.n_units <= FOLD_LDS_UNITS) hipLaunchKernelGGL(k_fold<true>, grid, block, 0, st, s->dev, A);
-            else hipLaunchKernelGGL(k_fold<false>, grid, block, 0, st, s->dev, A);
-        } else if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
+        if (s->shade_lds) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, st, s->dev, A);
         else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, st, s->dev, A);
     }
     if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 3], st));
@@ -3006,7 +2887,7 @@ int collect(Workspace& w, size_t n_slots, std::vector<ChunkStatus>& out, RunTota
 void add_stats(RunTotals& tot, const ChunkStatus& c) {
     tot.secondary += c.secondary; tot.shadow += c.shadow; tot.shade += c.shade;
     tot.flop_trace += c.flop_trace; tot.flop_shadow += c.flop_shadow; tot.flop_light += c.flop_light;
-    tot.mesh_nodes += c.mesh_nodes; tot.mesh_tris += c.mesh_tris; tot.flop_fold += c.flop_fold;
+    tot.mesh_nodes += c.mesh_nodes; tot.mesh_tris += c.mesh_tris;
     tot.levels = std::max(tot.levels, c.levels);
 }
 
@@ -3026,7 +2907,7 @@ void print_phases(Workspace& w) {
     (void)hipMemset(w.stats, 0, STAT_SHARDS * sizeof(StatShard));
     unsigned long long ph[8] = {0};
     for (const StatShard& sh : shards) for (int k = 0; k < 8; k++) ph[k] += sh.phase[k];
-    static const char* names[8] = {"(step end)", "ray", "walk", "material", "containers", "geometry", "spawn+post", "shading+pickup+stores"};
+    static const char* names[8] = {"shadows", "ray", "walk", "material", "containers", "geometry", "spawn+sync", "stores"};
     for (int k = 0; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
 }
 #endif
@@ -3655,7 +3536,6 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->flop_light = tot.flop_light;
         stats->mesh_nodes = tot.mesh_nodes;
         stats->mesh_tris = tot.mesh_tris;
-        stats->flop_fold = tot.flop_fold;
         stats->fused_shadows = fused_shadows(s, uses_lane_walk(s)) ? 1 : 0;
     }
     return RT_OK;
