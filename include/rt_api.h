@@ -202,6 +202,24 @@ int rt_colour_at(rt_scene *scene, uint32_t n, const double *rays, uint32_t depth
                  const uint64_t *seeds, double *out_rgb);
 
 /*
+ * Material::lighting (src/material.rs:47-87) for caller-supplied shade points,
+ * as the reference's unit tests call it.  Per point 12 f64, host memory: leaf
+ * index of the object, light index, point, eye vector, normal vector,
+ * intensity.  The generator of point i is seeded with seeds[i] (area lights;
+ * NULL: 0) and stands at lighting's own first draw.  out_rgb: n*3 f64.
+ */
+int rt_lighting(rt_scene *scene, uint32_t n, const double *in, const uint64_t *seeds, double *out_rgb);
+
+/*
+ * Lightable::intensity_at (src/light/point.rs:27-38, src/light/area.rs:75-90)
+ * of light `light` at n points (n*3 f64, host memory), one call after the
+ * other on ONE generator seeded with `seed`, as src/light/area.rs:164-198
+ * does.  The reference's walk, without device-only shortcuts.  out: n f64.
+ */
+int rt_intensity_at(rt_scene *scene, uint32_t light, uint32_t n, const double *points, uint64_t seed,
+                    double *out);
+
+/*
  * rt_colour_at for callers that cannot allocate (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
  * in the reference.  Same kernels and bit-identical colours as rt_colour_at, but

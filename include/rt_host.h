@@ -69,6 +69,15 @@ int rth_render(void *scene, uint32_t depth, const uint64_t *row_seeds, const rt_
 int rth_colour_at(void *scene, uint32_t n, const double *rays, uint32_t depth, const uint64_t *seeds,
                   double *out_rgb);
 int rth_probe(void *scene, uint32_t n, const double *rays, double *out);
+/* Material::lighting (src/material.rs:47-87) and Lightable::intensity_at
+ * (src/light/area.rs:75-90) for caller-supplied points; arguments as rt_lighting
+ * and rt_intensity_at. */
+int rth_lighting(void *scene, uint32_t n, const double *in, const uint64_t *seeds, double *out_rgb);
+int rth_intensity_at(void *scene, uint32_t light, uint32_t n, const double *points, uint64_t seed, double *out);
+/* Matrix::invert and determinant of a row-major 4x4
+ * (src/math/transformation/matrix.rs:99-123,227-245); RT_ERR_INVALID for a
+ * matrix the reference refuses to invert. */
+int rth_matrix_inverse(const double *in16, double *out16, double *det);
 
 /* Output writers; rgb8 is width*height*3 bytes, row-major. */
 int rth_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);

@@ -720,6 +720,57 @@ int orc_probe(void* h, uint32_t n, const double* rays, double* out) {
     return 0;
 }
 
+// Material::lighting (material.rs:47-87) called directly, as the reference's unit tests do.  Per
+// point 12 doubles: leaf index, light index, point, eye, normal, intensity; the rng of point i is
+// seeded with seeds[i].
+int orc_lighting(void* h, uint32_t n, const double* in, const uint64_t* seeds, double* out_rgb) {
+    auto* s = (OrcScene*)h;
+    std::vector<const Object*> leaves;
+    for (const Object& o : s->scene.objects) index_leaves(o, leaves);
+    try {
+        for (uint32_t i = 0; i < n; i++) {
+            const double* q = in + 12 * (size_t)i;
+            const size_t leaf = (size_t)q[0], light = (size_t)q[1];
+            if (leaf >= leaves.size() || light >= s->scene.lights.size()) { g_error = "index out of range"; return -1; }
+            Xoshiro256pp rng = Xoshiro256pp::seed_from_u64(seeds ? seeds[i] : 0);
+            const Object& o = *leaves[leaf];
+            V3 c = World::lighting(o.material, o, s->scene.lights[light], {q[2], q[3], q[4]}, {q[5], q[6], q[7]},
+                                   {q[8], q[9], q[10]}, q[11], rng);
+            out_rgb[3 * (size_t)i] = c.x; out_rgb[3 * (size_t)i + 1] = c.y; out_rgb[3 * (size_t)i + 2] = c.z;
+        }
+    } catch (const std::exception& e) { g_error = e.what(); return -1; }
+    return 0;
+}
+
+// Lightable::intensity_at (point.rs:27-38, area.rs:75-90) for n points, one call after the other on
+// one generator seeded with `seed` (the reference's test: light/area.rs:164-198).
+int orc_intensity_at(void* h, uint32_t light, uint32_t n, const double* points, uint64_t seed, double* out) {
+    auto* s = (OrcScene*)h;
+    if (light >= s->scene.lights.size()) { g_error = "index out of range"; return -1; }
+    try {
+        Xoshiro256pp rng = Xoshiro256pp::seed_from_u64(seed);
+        List scratch;
+        for (uint32_t i = 0; i < n; i++)
+            out[i] = s->world.intensity_at(s->scene.lights[light], {points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]},
+                                           rng, scratch);
+    } catch (const NanT&) { g_error = "NaN intersection distance while sorting"; return -5; }
+    catch (const std::exception& e) { g_error = e.what(); return -1; }
+    return 0;
+}
+
+// Matrix::invert and determinant (matrix.rs:99-123,227-245) of a row-major 4x4; returns -1 for a
+// matrix the reference refuses to invert.
+int orc_matrix_inverse(const double* in16, double* out16, double* det) {
+    Mat4 m;
+    std::memcpy(m.m, in16, sizeof m.m);
+    *det = det4(m);
+    try {
+        Mat4 r = invert(m);
+        std::memcpy(out16, r.m, sizeof r.m);
+    } catch (const std::exception& e) { g_error = e.what(); return -1; }
+    return 0;
+}
+
 // Colour::to_u8 (colour.rs:63-72): clamp, *255, round half away from zero; NaN -> 0.
 void orc_to_u8(const double* rgb, size_t n_values, uint8_t* out) {
     for (size_t i = 0; i < n_values; i++) {

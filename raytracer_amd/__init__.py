@@ -30,13 +30,14 @@ RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY, RT_ERR_NAN = -1
 ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
-    "rt_colour_at_noalloc", "rt_noalloc_max_rays",
+    "rt_colour_at_noalloc", "rt_noalloc_max_rays", "rt_lighting", "rt_intensity_at",
 )
 OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS = 1, 2, 3, 4, 5, 6
 HOST_ABI_SYMBOLS = (
     "rth_last_error", "rth_scene_from_file", "rth_scene_from_text", "rth_scene_spheres", "rth_scene_free",
     "rth_scene_info", "rth_scene_desc", "rth_camera", "rth_camera_nudge_half_view", "rth_row_seeds", "rth_upload",
     "rth_device_scene", "rth_render", "rth_colour_at", "rth_probe", "rth_write_ppm", "rth_write_png",
+    "rth_lighting", "rth_intensity_at", "rth_matrix_inverse",
 )
 
 
@@ -143,10 +144,23 @@ def host_lib():
                                  C.c_void_p]
         L.rth_colour_at.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.rth_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.rth_lighting.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rth_intensity_at.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.rth_matrix_inverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rth_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.rth_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         _host = L
     return _host
+
+
+def matrix_inverse(m):
+    """Matrix::invert / determinant of the host library (src/math/transformation/matrix.rs:99-123,227-245).
+    Returns (inverse or None for a matrix the reference refuses to invert, determinant)."""
+    a = np.ascontiguousarray(m, dtype=np.float64).reshape(4, 4)
+    out = np.zeros((4, 4), dtype=np.float64)
+    det = C.c_double()
+    rc = host_lib().rth_matrix_inverse(_ptr(a), _ptr(out), C.byref(det))
+    return (out if rc == RT_OK else None), det.value
 
 
 def init(device=0):
@@ -322,6 +336,26 @@ class Scene:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         out = np.zeros((rays.shape[0], 3), dtype=np.float64)
         rc = host_lib().rth_colour_at(self.h, rays.shape[0], _ptr(rays), depth, _ptr(seeds), _ptr(out))
+        if rc != RT_OK:
+            raise RtError(rc, host_lib().rth_last_error().decode())
+        return out
+
+    def lighting(self, points, seeds=None):
+        """Material::lighting (src/material.rs:47-87) for explicit shade points: rows of
+        (leaf, light, point xyz, eye xyz, normal xyz, intensity)."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 12)
+        out = np.zeros((pts.shape[0], 3), dtype=np.float64)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        rc = host_lib().rth_lighting(self.h, pts.shape[0], _ptr(pts), _ptr(sd), _ptr(out))
+        if rc != RT_OK:
+            raise RtError(rc, host_lib().rth_last_error().decode())
+        return out
+
+    def intensity_at(self, light, points, seed=0):
+        """Lightable::intensity_at (src/light/area.rs:75-90) at each point in turn, on one generator."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(pts.shape[0], dtype=np.float64)
+        rc = host_lib().rth_intensity_at(self.h, light, pts.shape[0], _ptr(pts), seed, _ptr(out))
         if rc != RT_OK:
             raise RtError(rc, host_lib().rth_last_error().decode())
         return out

@@ -170,6 +170,37 @@ int rth_probe(void* h, uint32_t n, const double* rays, double* out) {
     return rc;
 }
 
+// Material::lighting and Lightable::intensity_at for caller-supplied points (rt_lighting, rt_intensity_at)
+int rth_lighting(void* h, uint32_t n, const double* in, const uint64_t* seeds, double* out_rgb) {
+    auto* s = (HostScene*)h;
+    int rc = rth_upload(h);
+    if (rc != RT_OK) return rc;
+    rc = rt_lighting(s->device, n, in, seeds, out_rgb);
+    if (rc != RT_OK) g_error = rt_last_error();
+    return rc;
+}
+int rth_intensity_at(void* h, uint32_t light, uint32_t n, const double* points, uint64_t seed, double* out) {
+    auto* s = (HostScene*)h;
+    int rc = rth_upload(h);
+    if (rc != RT_OK) return rc;
+    rc = rt_intensity_at(s->device, light, n, points, seed, out);
+    if (rc != RT_OK) g_error = rt_last_error();
+    return rc;
+}
+// Matrix::invert and determinant of a row-major 4x4 (src/math/transformation/matrix.rs:99-123,227-245):
+// the routine every inverse handed to the device comes from, exposed so that the reference's known
+// answers can be run against it.  Returns RT_ERR_INVALID for a matrix the reference refuses to invert.
+int rth_matrix_inverse(const double* in16, double* out16, double* det) {
+    Mat4 m;
+    std::memcpy(m.m, in16, sizeof m.m);
+    *det = det4(m);
+    try {
+        Mat4 r = invert(m);
+        std::memcpy(out16, r.m, sizeof r.m);
+    } catch (const std::exception& e) { g_error = e.what(); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
 // Canvas::to_ppm (src/canvas.rs:50-60): "P3\nW H\n255\n" then one "r g b\n" per pixel.
 int rth_write_ppm(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height) {
     FILE* f = std::fopen(path, "wb");

@@ -1558,7 +1558,8 @@ __device__ __noinline__ double shade_pow(double x, double y) { return pow(x, y);
 // `rng` stands at the first of intensity_at's draws for this light (world.rs:61-69) and is left
 // behind lighting's own draws.
 DEV V3 lighting_one(const DevScene& S, uint32_t l, V3 pat, double m_ambient, double m_diffuse, double m_specular,
-                    double m_shininess, V3 over, V3 normal, V3 eye, double intensity, Rng& rng, uint32_t& flops) {
+                    double m_shininess, V3 over, V3 normal, V3 eye, double intensity, Rng& rng, uint32_t& flops,
+                    bool after_intensity_at = true) {
     // wave-uniform light data through the scalar cache
     const uint32_t usteps = clu(S.light_meta, l * 4 + 1), vsteps = clu(S.light_meta, l * 4 + 2);
     const uint32_t samples = usteps * vsteps;
@@ -1567,7 +1568,7 @@ DEV V3 lighting_one(const DevScene& S, uint32_t l, V3 pat, double m_ambient, dou
     const V3 uc = mk(cld(S.light, l * 12 + 3), cld(S.light, l * 12 + 4), cld(S.light, l * 12 + 5));
     const V3 vc = mk(cld(S.light, l * 12 + 6), cld(S.light, l * 12 + 7), cld(S.light, l * 12 + 8));
     const V3 lint = is_area ? mk(cld(S.light, l * 12 + 9), cld(S.light, l * 12 + 10), cld(S.light, l * 12 + 11)) : uc;
-    if (is_area) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
+    if (is_area && after_intensity_at) rng_skip(rng, 2 * samples);  // intensity_at's draws come first (world.rs:61-69)
     V3 col = cmul(pat, lint);
     V3 ambient = col * m_ambient;
     V3 diffuse = mk(0.0, 0.0, 0.0), specular = mk(0.0, 0.0, 0.0);
@@ -2310,6 +2311,49 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
     if (err) atomicOr(&counters->error, err);
 }
 
+// rt_lighting: Material::lighting (material.rs:47-87) for caller-supplied shade points, one per
+// thread.  Per point 12 f64: unit position of the object's leaf, light index, point, eye vector,
+// normal vector, intensity.  The rng of point i is seeded with seeds[i] and stands at lighting's
+// own first draw, as in a direct call of the reference's function.
+__global__ __launch_bounds__(64) void k_lighting(DevScene S, uint32_t n, const double* in, const unsigned long long* seeds,
+                                                 double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* q = in + (size_t)i * 12;
+    const uint32_t pos = (uint32_t)q[0], light = (uint32_t)q[1];
+    const V3 point = mk(q[2], q[3], q[4]), eye = mk(q[5], q[6], q[7]), normal = mk(q[8], q[9], q[10]);
+    const double* mat_rec = S.mat + (size_t)S.stream[(size_t)pos * 16 + 1] * 8;
+    PatTables pt;
+    pt.pat_meta = S.pat_meta; pt.pat_inv = S.pat_inv; pt.pat_col = S.pat_col;
+    const V3 object_point = mul_point_v(leaf_inverse(S.stream, S.xform, pos), point);
+    const V3 pat = pattern_eval(pt, (uint32_t)mat_rec[7], object_point);
+    Rng rng = rng_seed(seeds ? seeds[i] : 0ull);
+    uint32_t flops = 0;
+    const V3 c = lighting_one(S, light, pat, mat_rec[0], mat_rec[1], mat_rec[2], mat_rec[3], point, normal, eye, q[11], rng, flops, false);
+    out[(size_t)i * 3 + 0] = c.x; out[(size_t)i * 3 + 1] = c.y; out[(size_t)i * 3 + 2] = c.z;
+}
+
+// rt_intensity_at: Lightable::intensity_at (light/point.rs:27-38, light/area.rs:75-90) of one light
+// for n points, one call after the other on ONE generator, by one wave (the walk is the wave's; only
+// lane 0 holds a point).  The reference's walk, without any device-only shortcut.
+__global__ __launch_bounds__(64) void k_intensity_at(DevScene S, uint32_t light, uint32_t n, const double* points,
+                                                     unsigned long long seed, double* out, Counters* counters) {
+    LevelArgs A{};
+    A.intensity = out - (size_t)light * n;  // intensities() writes light l of record i at [l * rec_cap + i]
+    A.rec_cap = n;
+    const uint32_t samples = clu(S.light_meta, light * 4 + 1) * clu(S.light_meta, light * 4 + 2);
+    const bool is_area = clu(S.light_meta, light * 4 + 0) == RT_LIGHT_AREA;
+    Rng rng = rng_seed(seed);
+    Work flops{};
+    uint32_t err = 0, n_shadow = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const V3 p = mk(points[(size_t)i * 3 + 0], points[(size_t)i * 3 + 1], points[(size_t)i * 3 + 2]);
+        intensities<true, false, false>(S, A, threadIdx.x == 0, i, p, mk(0.0, 0.0, 0.0), rng, flops, err, n_shadow, light, light + 1u);
+        if (is_area) rng_skip(rng, 2 * samples);  // what positions() drew (light/area.rs:57-67)
+    }
+    if (err) atomicOr(&counters->error, err);
+}
+
 // ---------------------------------------------------------------- static scratch (rt_colour_at_noalloc)
 // Device memory for callers that must not allocate: the record arrays, level table, counters and
 // statistics lines of one small batch of rays are carved out of this array instead of a Workspace's
@@ -2655,6 +2699,7 @@ struct rt_scene {
     uint32_t min_chunks = 2;
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
+    std::vector<uint32_t> leaf_unit;    // unit position of every leaf's record (rt_lighting takes leaf indices)
 };
 
 namespace {
@@ -3263,6 +3308,9 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     (void)hipGetDevice(&s->device);
     s->has_csg = has_csg;
     s->has_area = has_area;
+    s->leaf_unit.assign(d->n_leaves, 0);
+    for (uint32_t i = 0; i < d->n_nodes; i++)
+        if (d->node_kind[i] == RT_NODE_LEAF) s->leaf_unit[d->node_arg[i]] = unit_of[i];
     auto keep = [&](void* p) { s->allocations.push_back(p); };
     int rc = RT_OK;
 #define UP(vec, field)                                       \
@@ -3581,6 +3629,64 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
     }
     (void)hipFree(d_out);
     return rc;
+}
+
+int rt_lighting(rt_scene* s, uint32_t n, const double* in, const uint64_t* seeds, double* out_rgb) {
+    if (!s || (n && (!in || !out_rgb))) return fail(RT_ERR_INVALID, "null argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<double> host(in, in + (size_t)n * 12);
+    std::vector<unsigned long long> host_seeds(n, 0ull);
+    for (uint32_t i = 0; i < n; i++) {
+        double* q = &host[(size_t)i * 12];
+        if (!(q[0] >= 0.0 && q[0] < (double)s->leaf_unit.size())) return fail(RT_ERR_INVALID, "leaf index out of range");
+        if (!(q[1] >= 0.0 && q[1] < (double)s->dev.n_lights)) return fail(RT_ERR_INVALID, "light index out of range");
+        q[0] = (double)s->leaf_unit[(size_t)q[0]];
+        if (seeds) host_seeds[i] = seeds[i];
+    }
+    double *d_in = nullptr, *d_out = nullptr;
+    unsigned long long* d_seeds = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, host.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_seeds, (size_t)n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpy(d_in, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_seeds, host_seeds.data(), (size_t)n * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_lighting, dim3((n + 63) / 64), dim3(64), 0, nullptr, s->dev, n, d_in, d_seeds, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out_rgb, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_seeds);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_intensity_at(rt_scene* s, uint32_t light, uint32_t n, const double* points, uint64_t seed, double* out) {
+    if (!s || (n && (!points || !out))) return fail(RT_ERR_INVALID, "null argument");
+    if (light >= s->dev.n_lights) return fail(RT_ERR_INVALID, "light index out of range");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    double *d_pts = nullptr, *d_out = nullptr;
+    Counters* d_counters = nullptr;
+    hipError_t e = hipMalloc((void**)&d_pts, (size_t)n * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_counters, sizeof(Counters));
+    if (e == hipSuccess) e = hipMemset(d_counters, 0, sizeof(Counters));
+    if (e == hipSuccess) e = hipMemcpy(d_pts, points, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_intensity_at, dim3(1), dim3(64), 0, nullptr, s->dev, light, n, d_pts, (unsigned long long)seed, d_out, d_counters);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    Counters c{};
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&c, d_counters, sizeof c, hipMemcpyDeviceToHost);
+    (void)hipFree(d_pts); (void)hipFree(d_out); (void)hipFree(d_counters);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, hipGetErrorString(e));
+    if (c.error & 2u) return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed");
+    if (c.error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
+    return RT_OK;
 }
 
 uint32_t rt_noalloc_max_rays(void) { return RT_NOALLOC_MAX_RAYS; }

@@ -41,6 +41,9 @@ def lib():
         L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_colour_at.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_lighting.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_intensity_at.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_matrix_inverse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ray_for_pixel.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_to_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_rng_gen_range.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_void_p]
@@ -137,10 +140,33 @@ class OracleScene:
             raise RuntimeError(lib().orc_last_error().decode())
         return out
 
+    def lighting(self, points, seeds=None):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 12)
+        out = np.zeros((pts.shape[0], 3), dtype=np.float64)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint64)
+        if lib().orc_lighting(self.h, pts.shape[0], _ptr(pts), _ptr(sd), _ptr(out)) != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return out
+
+    def intensity_at(self, light, points, seed=0):
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(pts.shape[0], dtype=np.float64)
+        if lib().orc_intensity_at(self.h, light, pts.shape[0], _ptr(pts), seed, _ptr(out)) != 0:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return out
+
     def ray_for_pixel(self, x, y):
         out = np.zeros(6, dtype=np.float64)
         lib().orc_ray_for_pixel(self.h, x, y, _ptr(out))
         return out
+
+
+def matrix_inverse(m):
+    a = np.ascontiguousarray(m, dtype=np.float64).reshape(4, 4)
+    out = np.zeros((4, 4), dtype=np.float64)
+    det = C.c_double()
+    rc = lib().orc_matrix_inverse(_ptr(a), _ptr(out), C.byref(det))
+    return (out if rc == 0 else None), det.value
 
 
 def to_u8(rgb):

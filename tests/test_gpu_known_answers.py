@@ -35,6 +35,61 @@ def test_prepare_computations():
     cc.check_prepare(make)
 
 
+def test_bounding_boxes():
+    cc.check_bounding_boxes(make)
+
+
+def test_csg_truth_tables_and_filter():
+    cc.check_csg(make)
+
+
+def test_groups():
+    cc.check_groups(make)
+
+
+def test_list_hits():
+    cc.check_list_hits(make)
+
+
+def test_triangles():
+    cc.check_triangles(make)
+
+
+def test_lighting():
+    cc.check_lighting(make)
+
+
+def test_intensity_at():
+    cc.check_intensity_at(make)
+
+
+def test_patterns():
+    cc.check_patterns(make)
+
+
+def test_lighting_and_intensity_are_bit_exact_against_the_oracle():
+    rng = np.random.default_rng(5)
+    for text, lights in ((ka.LIGHTING_WORLD, 3), (ka.AREA_LIGHTING_WORLD, 1), (ka.AREA_INTENSITY_WORLD, 1)):
+        n = 500
+        leaves = 3 if text is ka.LIGHTING_WORLD else (1 if text is ka.AREA_LIGHTING_WORLD else 2)
+        rows = np.zeros((n, 12))
+        rows[:, 0] = rng.integers(0, leaves, n)
+        rows[:, 1] = rng.integers(0, lights, n)
+        rows[:, 2:5] = rng.uniform(-3, 3, (n, 3))
+        for c in (5, 8):
+            v = rng.normal(size=(n, 3))
+            rows[:, c:c + 3] = v / np.sqrt((v * v).sum(axis=1, keepdims=True))
+        rows[:, 11] = rng.integers(0, 5, n) / 4.0
+        seeds = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+        a = make(text).lighting(rows, seeds)
+        b = ol.OracleScene.from_text(text).lighting(rows, seeds)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), text
+        pts = rng.uniform(-3, 3, (200, 3))
+        a = make(text).intensity_at(0, pts, 11)
+        b = ol.OracleScene.from_text(text).intensity_at(0, pts, 11)
+        assert np.array_equal(a, b), text
+
+
 def test_empty_ray_list_and_miss():
     s = make(ka.TEST_WORLD)
     assert s.colour_at(np.zeros((0, 6)), 5).shape == (0, 3)

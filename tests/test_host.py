@@ -64,6 +64,17 @@ def test_loading_the_reference_fixture_scene():  # scene/mod.rs:309-340 (src/sce
     assert math.isclose(cam.half_width, math.tan(math.pi / 6)) and math.isclose(cam.pixel_size, cam.half_width * 2 / 500)
 
 
+def test_matrix_inverses_of_the_host_library():  # matrix.rs:717-829
+    import common_cases as cc
+    cc.check_matrix_inverses(ra.matrix_inverse)
+    rng = np.random.default_rng(3)
+    for _ in range(50):     # the host library and the oracle invert alike, to the bit
+        m = rng.uniform(-5, 5, (4, 4))
+        a, da = ra.matrix_inverse(m)
+        b, db = ol.matrix_inverse(m)
+        assert da == db and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_scale_truncates():  # camera.rs:78-87
     s = ra.Scene.from_text(ka.TEST_WORLD, scale=0.37)
     assert (s.width, s.height) == (4, 4)

@@ -30,6 +30,42 @@ def test_prepare_computations():
     cc.check_prepare(make)
 
 
+def test_bounding_boxes():
+    cc.check_bounding_boxes(make)
+
+
+def test_csg_truth_tables_and_filter():
+    cc.check_csg(make)
+
+
+def test_groups():
+    cc.check_groups(make)
+
+
+def test_list_hits():
+    cc.check_list_hits(make)
+
+
+def test_triangles():
+    cc.check_triangles(make)
+
+
+def test_lighting():
+    cc.check_lighting(make)
+
+
+def test_intensity_at():
+    cc.check_intensity_at(make)
+
+
+def test_patterns():
+    cc.check_patterns(make)
+
+
+def test_matrix_inverses():
+    cc.check_matrix_inverses(ol.matrix_inverse)
+
+
 def test_camera_rays():  # camera.rs:265-366
     for view, (x, y), origin, direction in ka.CAMERA_CASES:
         s = make(ka.camera_scene(view))
