@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=768, help="rows of the frame the CPU oracle renders for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-frames", action="store_true", help="skip the frames rendered into host memory after the timed region")
     ap.add_argument("--streams", type=int, default=2, help="image-row chunks in flight at once (1..4)")
     ap.add_argument("--grid-blocks", type=int, default=None)
     ap.add_argument("--traversal", type=int, default=None, help="0 auto, 1 wave-uniform, 2 per lane, 3 the reference walk (no device-only shortcut)")
@@ -234,6 +235,14 @@ def main():
                     "achieved_GBs": mesh_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
                     "note": "served by the L2 / Infinity Cache (the hierarchies are a few MB), so a latency figure, not an HBM one",
                 }
+            # k_trace's own share of the algorithmic bytes above: it reads a secondary ray's origin and direction (48 B)
+            # and writes hit_pos (12 B per ray), each child's origin and direction (48 B), a primary ray's direction
+            # (24 B), and per shade point over_point + normal (48 B), the child links (8 B) and one intensity per light
+            alg_trace = 48 * secondary + 12 * (primary + secondary) + 48 * secondary + 24 * primary + \
+                (48 + 8 + (8 * n_lights if fused else 0)) * shade
+            out["roofline"]["traffic"], out["roofline"]["traffic_detail"] = measured_traffic(args, launches, alg_trace)
+            if not args.no_host_frames:
+                out.update(host_frames(ra, scene, depth, seeds, H, W, frame))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"], out["parity_on_sample"] = cpu_baseline(args, scene_file, scale, depth, frame, H)
         print(json.dumps(out), flush=True)
@@ -242,13 +251,100 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(args, launches, alg_trace):
+    """HBM-side bytes of k_trace per launch from the committed counter passes of this same command
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each; tools/collect_profiles.sh and
+    tools/summarise_profiles.py).  Counters cannot be read from inside the process, so the line
+    carries the newest committed profile of the headline workload and says which."""
+    import glob
+    if not (args.workload.startswith("chapter11-10000") and args.scale is None and args.depth is None) or not launches:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    k = t["kernels"].get("k_trace")
+    if not k:
+        return None, None
+    per_launch = (k["fetch_bytes_corrected"] + k["write_bytes"]) / k["launches"]
+    detail = dict(k)
+    detail.update({"algorithmic_bytes_k_trace_per_frame": alg_trace,
+                   "measured_over_algorithmic": (k["fetch_bytes_corrected"] + k["write_bytes"]) / alg_trace if alg_trace else None})
+    detail.update({"source": os.path.relpath(files[-1], ROOT), "unit": "bytes per frame (k_trace launches summed)",
+                   "correction": t.get("correction"), "other_kernels": {n: v for n, v in t["kernels"].items() if n != "k_trace"}})
+    return per_launch, detail
+
+
+def host_frames(ra, scene, depth, seeds, H, W, frame8_dev):
+    """Frames delivered to host memory, as the reference's Camera::render returns its Canvas: wall time of
+    rt_render with host outputs, outside the timed region.  `pinned`: the caller page-locked its buffer once
+    (rt_host_register); `pageable`: an ordinary buffer, which rt_render locks for the length of each call."""
+    out = {}
+    rgb8 = np.empty((H, W, 3), dtype=np.uint8)
+    rgb8[:] = 0   # touch every page before any timing
+    rgb = np.empty((H, W, 3), dtype=np.float64)
+    rgb[:] = 0
+
+    def timed(a, b, reps=2):
+        scene.render_into(depth, seeds, None, a, b)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            scene.render_into(depth, seeds, None, a, b)
+        return 1e3 * (time.perf_counter() - t0) / reps
+
+    out["frame_ms_host_u8_pageable"] = timed(None, rgb8)
+    out["frame_ms_host_f64_pageable"] = timed(rgb, None)
+    same = bool((rgb8 == frame8_dev.cpu().numpy()).all())
+    del rgb
+    rgb8 = ra.host_empty((H, W, 3), np.uint8)
+    rgb = ra.host_empty((H, W, 3), np.float64)
+    out["frame_ms_host_u8"] = timed(None, rgb8)
+    out["frame_ms_host_f64"] = timed(rgb, None)
+    out["host_frames_note"] = ("rt_render into host memory, whole frame, mean of 2 after 1 warm-up; *_host_u8 / *_host_f64: the "
+                               "caller's buffer is page-locked (rt_host_alloc), chunks arrive as they finish; *_pageable: "
+                               "ordinary memory, filled through the library's page-locked staging buffer and a threaded memcpy")
+    same = same and bool((rgb8 == frame8_dev.cpu().numpy()).all())
+    out["host_u8_equals_device_u8"] = same
+    return out
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """Threads this process may keep busy: its affinity mask, cut to the cgroup's CPU quota and to the
+    OMP_NUM_THREADS the box sets as the share of one GPU's job."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "affinity mask"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < n:
+                n, why = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and 0 < int(env) < n:
+        n, why = int(env), "OMP_NUM_THREADS set by the box (one GPU's share of the host)"
+    return n, why
+
+
 def cpu_baseline(args, scene_file, scale, depth, frame8, height):
     """Time the CPU oracle (a port of the reference's algorithm, row-parallel with dynamic
     scheduling like its rayon path) on evenly spaced rows of the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
-    cores = min(16, os.cpu_count() or 1)
+    cores, cores_rule = usable_cores()
     if scene_file is None:
         o = ol.OracleScene.spheres(scale, args.seed)
     else:
@@ -269,6 +365,7 @@ def cpu_baseline(args, scene_file, scale, depth, frame8, height):
         "sample": "%d evenly spaced rows of the same %dx%d frame (%d primary + %d secondary rays) in %.2f s"
         % (len(rows), o.width, height, len(rows) * o.width, c["secondary"], dt),
         "projected_frame_s": dt * height / len(rows),
+        "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "cores_rule": cores_rule,
     }
     parity = {"rows": int(len(rows)), "pixels": int(len(rows) * o.width), "u8_mismatch_pixels": mism}
     return base, parity

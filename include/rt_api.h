@@ -188,10 +188,24 @@ void rt_scene_destroy(rt_scene *scene);
  *   out_rgb8   rows*width*3 bytes of Colour::to_u8 (src/colour.rs:63-72), or NULL
  *   out_on_device  non-zero when the two output pointers are device memory
  *   stats      optional
+ * Host outputs receive each chunk of rows as it is finished, beside the next
+ * chunk's kernels.  Page-locked memory (rt_host_alloc, hipHostMalloc) is
+ * written directly; ordinary memory is locked for the length of the call where
+ * the driver allows that (RT_OPT_PIN_OUTPUTS) and is otherwise filled through
+ * a page-locked staging buffer the scene keeps.  A call that fails returns
+ * only after every kernel and copy it queued has ended.
  */
 int rt_render(rt_scene *scene, const rt_camera *camera, uint32_t depth, const uint64_t *row_seeds,
               const rt_partition *part, double *out_rgb, uint8_t *out_rgb8, int out_on_device,
               rt_stats *stats);
+
+/*
+ * Page-locked host memory for the outputs of rt_render (the pixels of a Canvas,
+ * src/canvas.rs:7-11): the device writes finished chunks straight into it, with
+ * no staging copy.  No counterpart in the reference.
+ */
+int rt_host_alloc(void **out, size_t bytes);
+int rt_host_free(void *buffer);
 
 /*
  * World::colour_at for caller-supplied rays (src/world.rs:33-49): n rays of
@@ -273,9 +287,12 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *                          three are checked against)
  *   RT_OPT_MIN_CHUNKS      a frame of two megapixels or more is cut into at least
  *                          this many chunks (default 2)
+ *   RT_OPT_PIN_OUTPUTS     1 (default): rt_render tries to page-lock ordinary host
+ *                          outputs for the length of the call; 0: it goes straight
+ *                          to its staging buffer
  */
 enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, RT_OPT_GRID_BLOCKS = 4,
-       RT_OPT_TRAVERSAL = 5, RT_OPT_MIN_CHUNKS = 6 };
+       RT_OPT_TRAVERSAL = 5, RT_OPT_MIN_CHUNKS = 6, RT_OPT_PIN_OUTPUTS = 7 };
 int rt_set_option(rt_scene *scene, int option, uint64_t value);
 
 /* Limits of this build (per-ray list bounds). */

@@ -31,8 +31,9 @@ ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
     "rt_colour_at_noalloc", "rt_noalloc_max_rays", "rt_lighting", "rt_intensity_at",
+    "rt_host_alloc", "rt_host_free",
 )
-OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS = 1, 2, 3, 4, 5, 6
+OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS, OPT_PIN_OUTPUTS = 1, 2, 3, 4, 5, 6, 7
 HOST_ABI_SYMBOLS = (
     "rth_last_error", "rth_scene_from_file", "rth_scene_from_text", "rth_scene_spheres", "rth_scene_free",
     "rth_scene_info", "rth_scene_desc", "rth_camera", "rth_camera_nudge_half_view", "rth_row_seeds", "rth_upload",
@@ -111,6 +112,8 @@ def hip_lib():
         L.rt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.rt_colour_at_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.rt_noalloc_max_rays.restype = C.c_uint32
+        L.rt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.rt_host_free.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -161,6 +164,32 @@ def matrix_inverse(m):
     det = C.c_double()
     rc = host_lib().rth_matrix_inverse(_ptr(a), _ptr(out), C.byref(det))
     return (out if rc == RT_OK else None), det.value
+
+
+class _HostBlock:
+    """Owner of one rt_host_alloc allocation; numpy arrays made over it keep it alive."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        rc = hip_lib().rt_host_alloc(C.byref(self.ptr), max(1, nbytes))
+        if rc != RT_OK:
+            raise RtError(rc, hip_lib().rt_last_error().decode())
+        self.nbytes = nbytes
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _hip is not None:
+            _hip.rt_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_empty(shape, dtype):
+    """A numpy array in page-locked host memory (rt_host_alloc) for Scene.render_into to fill."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    block = _HostBlock(n)
+    buf = (C.c_ubyte * max(1, n)).from_address(block.ptr.value)
+    buf._owner = block
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def init(device=0):
@@ -303,7 +332,7 @@ class Scene:
 
     def set_option(self, option, value):
         """rt_set_option on the uploaded scene (OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS,
-        OPT_TRAVERSAL: 0 auto, 1 wave walk, 2 lane walk, 3 the reference's walk; OPT_MIN_CHUNKS)."""
+        OPT_TRAVERSAL: 0 auto, 1 wave walk, 2 lane walk, 3 the reference's walk; OPT_MIN_CHUNKS, OPT_PIN_OUTPUTS)."""
         rc = hip_lib().rt_set_option(self.upload(), option, value)
         if rc != RT_OK:
             raise RtError(rc, hip_lib().rt_last_error().decode())
@@ -321,6 +350,15 @@ class Scene:
         if rc != RT_OK:
             raise RtError(rc, host_lib().rth_last_error().decode())
         return Canvas(self.width, rows, rgb, rgb8), stats.as_dict()
+
+    def render_into(self, depth, row_seeds, part, rgb, rgb8):
+        """Render into host arrays the caller owns (either may be None); returns the stats dict."""
+        stats = Stats()
+        rc = host_lib().rth_render(self.h, depth, _ptr(row_seeds), C.byref(part) if part is not None else None,
+                                   _ptr(rgb), _ptr(rgb8), 0, C.byref(stats))
+        if rc != RT_OK:
+            raise RtError(rc, host_lib().rth_last_error().decode())
+        return stats.as_dict()
 
     def render_device(self, depth, row_seeds, part, out_rgb_ptr, out_rgb8_ptr):
         """Render into device buffers (raw pointers); returns the stats dict."""

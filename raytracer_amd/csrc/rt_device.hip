@@ -45,6 +45,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_api.h"
@@ -2694,6 +2695,11 @@ struct rt_scene {
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
     size_t stage_pixels = 0;
+    hipStream_t copy_stream = nullptr;  // host outputs: finished chunks go to the caller's memory beside the next one's kernels
+    std::vector<hipEvent_t> copy_ev;
+    bool pin_outputs = true;            // page-lock pageable host outputs for the length of the call, where the driver can
+    void* bounce[2] = {nullptr, nullptr};   // page-locked staging for pageable host outputs (f64, u8)
+    size_t bounce_bytes[2] = {0, 0};
     size_t chunk_pixels = (size_t)26 << 20;
     size_t recs_per_pixel = 24;
     uint32_t min_chunks = 2;
@@ -2956,6 +2962,27 @@ void print_phases(Workspace& w) {
     for (int k = 0; k < 8; k++) std::fprintf(stderr, "phase %-11s %.3e ticks\n", names[k], (double)ph[k]);
 }
 #endif
+
+// memcpy over a few threads: one thread moves about 10 GB/s, a frame of f64 pixels is 1.2 GB.
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n = bytes < ((size_t)8 << 20) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    if (n <= 1) { std::memcpy(dst, src, bytes); return; }
+    const size_t slice = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+    std::vector<std::thread> pool;
+    for (size_t off = slice; off < bytes; off += slice)
+        pool.emplace_back([=] { std::memcpy((char*)dst + off, (const char*)src + off, std::min(slice, bytes - off)); });
+    std::memcpy(dst, src, std::min(slice, bytes));
+    for (auto& t : pool) t.join();
+}
+
+// Whether the HIP runtime knows `p` as page-locked host memory (hipHostMalloc, hipHostRegister): copies into
+// such memory can be asynchronous and run at the link's rate.
+bool host_page_locked(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 
 uint32_t local_rows(const rt_camera* cam, const rt_partition* p) {
     if (!p || p->world <= 1) return cam->height;
@@ -3393,7 +3420,23 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->stage_rgb) (void)hipFree(s->stage_rgb);
     if (s->stage_rgb8) (void)hipFree(s->stage_rgb8);
     if (s->seeds) (void)hipFree(s->seeds);
+    for (hipEvent_t e : s->copy_ev) (void)hipEventDestroy(e);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    for (void* b : s->bounce) if (b) (void)hipHostFree(b);
     delete s;
+}
+
+int rt_host_alloc(void** out, size_t bytes) {
+    if (!out || !bytes) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return RT_OK;
+}
+
+int rt_host_free(void* p) {
+    if (!p) return RT_OK;
+    HIP_TRY(hipHostFree(p));
+    return RT_OK;
 }
 
 int rt_set_option(rt_scene* s, int option, uint64_t value) {
@@ -3425,6 +3468,9 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
         case RT_OPT_MIN_CHUNKS:
             if (value < 1 || value > 64) return fail(RT_ERR_INVALID, "min_chunks must be in 1..64");
             s->min_chunks = (uint32_t)value;
+            return RT_OK;
+        case RT_OPT_PIN_OUTPUTS:
+            s->pin_outputs = value != 0;
             return RT_OK;
         case RT_OPT_GRID_BLOCKS:
             if (value > 65536) return fail(RT_ERR_INVALID, "grid_blocks must be in 0..65536 (0: chosen by the number of streams)");
@@ -3461,6 +3507,13 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     double* d_rgb = out_rgb;
     uint8_t* d_rgb8 = out_rgb8;
     size_t total_px = (size_t)rows * W;
+    // Host outputs: page-locked memory (the caller's own, or locked here for the length of the call) takes each
+    // chunk as it finishes, on a stream of its own, while the next chunk's kernels run; memory that cannot be
+    // locked is filled by one pageable copy at the end.
+    bool host_async = false;
+    void* locked_here[2] = {nullptr, nullptr};
+    unsigned char* async_dst[2] = {nullptr, nullptr};  // where the asynchronous copies land (f64, u8)
+    bool via_bounce[2] = {false, false};
     if (!out_on_device && total_px > 0) {
         if (s->stage_pixels < total_px) {
             if (s->stage_rgb) HIP_TRY(hipFree(s->stage_rgb));
@@ -3473,8 +3526,32 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         }
         d_rgb = out_rgb ? s->stage_rgb : nullptr;
         d_rgb8 = out_rgb8 ? s->stage_rgb8 : nullptr;
+        void* outs[2] = {out_rgb, out_rgb8};
+        const size_t bytes[2] = {total_px * 3 * sizeof(double), total_px * 3};
+        host_async = true;
+        for (int k = 0; k < 2 && host_async; k++) {
+            async_dst[k] = (unsigned char*)outs[k];
+            if (!outs[k] || host_page_locked(outs[k])) continue;
+            if (s->pin_outputs && hipHostRegister(outs[k], bytes[k], hipHostRegisterDefault) == hipSuccess) { locked_here[k] = outs[k]; continue; }
+            (void)hipGetLastError();
+            // not lockable in place (some drivers refuse ordinary memory): stage through the scene's own page-locked buffer
+            if (s->bounce_bytes[k] < bytes[k]) {
+                if (s->bounce[k]) (void)hipHostFree(s->bounce[k]);
+                s->bounce[k] = nullptr; s->bounce_bytes[k] = 0;
+                if (hipHostMalloc(&s->bounce[k], bytes[k], hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); s->bounce[k] = nullptr; host_async = false; break; }
+                s->bounce_bytes[k] = bytes[k];
+            }
+            async_dst[k] = (unsigned char*)s->bounce[k];
+            via_bounce[k] = true;
+        }
+        if (host_async && !s->copy_stream) {
+            if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); host_async = false; }
+        }
     }
+    const size_t recs_per_pixel_before = s->recs_per_pixel;
+    size_t copies = 0;
 
+    auto frame = [&]() -> int {
     // row chunks: multiples of 8 rows, at most chunk_pixels pixels.  Each pass queues every
     // pending chunk (alternating over the workspaces so two chunks overlap on the GPU), then
     // waits; chunks whose rays did not fit their record arrays are split and go round again.
@@ -3501,9 +3578,12 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     if (n_chunks > 1) n_chunks = (n_chunks + n_ws - 1) / n_ws * n_ws;
     uint32_t chunk_rows = std::max(8u, (uint32_t)(((rows + n_chunks - 1) / n_chunks + 7) & ~(size_t)7));
     struct Job { uint32_t r0, nr; };
+    struct Arrival { hipEvent_t copied; size_t at, n; };  // a chunk's outputs: first element and element count
     std::vector<Job> pending;
+    std::vector<Arrival> arrivals;
     for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0)});
     while (!pending.empty()) {
+        copies = 0;
         std::vector<Job> queued[MAX_STREAMS];
         size_t max_px = 0;
         for (const Job& j : pending) max_px = std::max(max_px, (size_t)j.nr * W);
@@ -3527,7 +3607,33 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
                                           queued[k].size(), tot);
             if (rc != RT_OK) return rc;
             queued[k].push_back(j);
+            if (host_async) {
+                // a chunk that has to go round again is copied again behind this copy, on the same stream
+                while (s->copy_ev.size() <= copies + 1) {
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    s->copy_ev.push_back(e);
+                }
+                hipEvent_t done = s->copy_ev[copies], copied = s->copy_ev[copies + 1];
+                copies += 2;
+                HIP_TRY(hipEventRecord(done, s->ws[k].stream));
+                HIP_TRY(hipStreamWaitEvent(s->copy_stream, done, 0));
+                const size_t at = (size_t)j.r0 * W * 3, n = (size_t)j.nr * W * 3;
+                if (out_rgb) HIP_TRY(hipMemcpyAsync(async_dst[0] + at * sizeof(double), d_rgb + at, n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+                if (out_rgb8) HIP_TRY(hipMemcpyAsync(async_dst[1] + at, d_rgb8 + at, n, hipMemcpyDeviceToHost, s->copy_stream));
+                HIP_TRY(hipEventRecord(copied, s->copy_stream));
+                arrivals.push_back({copied, at, n});
+            }
         }
+        // staged outputs: move each chunk on to the caller's memory as it arrives, while later chunks render
+        if (via_bounce[0] || via_bounce[1]) {
+            for (const Arrival& a : arrivals) {
+                HIP_TRY(hipEventSynchronize(a.copied));
+                if (via_bounce[0] && out_rgb) parallel_copy(out_rgb + a.at, async_dst[0] + a.at * sizeof(double), a.n * sizeof(double));
+                if (via_bounce[1] && out_rgb8) parallel_copy(out_rgb8 + a.at, async_dst[1] + a.at, a.n);
+            }
+        }
+        arrivals.clear();
         pending.clear();
         bool grow_budget = false;
         for (int k = 0; k < n_ws; k++) {
@@ -3554,6 +3660,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
             }
         }
         if (grow_budget) {
+            // kept for the scene's later frames when this one succeeds: they would overflow the same way
             if (s->recs_per_pixel >= 4096) return fail(RT_ERR_CAPACITY, "the record arrays overflow even for an 8-row chunk");
             s->recs_per_pixel *= 4;
         }
@@ -3561,10 +3668,27 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
 #ifdef RT_PHASE_TIMERS
     for (int k = 0; k < n_ws; k++) print_phases(s->ws[k]);
 #endif
-    if (!out_on_device) {
+    if (host_async) {
+        HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    } else if (!out_on_device) {
         if (out_rgb) HIP_TRY(hipMemcpy(out_rgb, d_rgb, total_px * 3 * sizeof(double), hipMemcpyDeviceToHost));
         if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, d_rgb8, total_px * 3, hipMemcpyDeviceToHost));
     }
+    return RT_OK;
+    };
+    int frame_rc = frame();
+    std::string frame_error;
+    if (frame_rc != RT_OK) {
+        // Nothing of this frame may still run when the caller gets its buffers back: wait for every stream that
+        // has work of it, whatever the waits themselves return, and keep the first error's message.
+        frame_error = g_error;
+        for (int k = 0; k < MAX_STREAMS; k++) if (s->ws[k].stream) (void)hipStreamSynchronize(s->ws[k].stream);
+        if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+        (void)hipGetLastError();
+        s->recs_per_pixel = recs_per_pixel_before;
+    }
+    for (void* q : locked_here) if (q) (void)hipHostUnregister(q);
+    if (frame_rc != RT_OK) { g_error = frame_error; return frame_rc; }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);

@@ -89,6 +89,34 @@ def test_row_partition_renders_the_same_pixels():
         assert np.array_equal(frame.view(np.uint64), whole.pixels.view(np.uint64))
 
 
+def test_host_outputs_arrive_whole_whatever_the_buffer():
+    """Host outputs are filled chunk by chunk while later chunks render when the buffer is page-locked (by the
+    caller, or by rt_render for the call) and by one pageable copy otherwise: the same bytes every way, also
+    when chunks overflow their record arrays and are rendered again."""
+    g, _ = pair("scenes/chapter11.yaml", 0.5)
+    seeds = g.row_seeds()
+    base, _ = g.render(10, seeds)
+    shape = base.pixels.shape
+    for opts in ({}, {ra.OPT_PIN_OUTPUTS: 0}, {ra.OPT_CHUNK_PIXELS: 16 * g.width, ra.OPT_RECS_PER_PIXEL: 1},
+                 {ra.OPT_STREAMS: 1, ra.OPT_CHUNK_PIXELS: 8 * g.width}):
+        h, _ = pair("scenes/chapter11.yaml", 0.5)
+        for k, v in opts.items():
+            h.set_option(k, v)
+        for locked in (False, True):
+            if locked:
+                rgb, rgb8 = ra.host_empty(shape, np.float64), ra.host_empty(shape, np.uint8)
+            else:
+                rgb, rgb8 = np.empty(shape), np.empty(shape, dtype=np.uint8)
+            rgb[:] = -1.0
+            rgb8[:] = 7
+            h.render_into(10, seeds, None, rgb, rgb8)
+            assert np.array_equal(rgb.view(np.uint64), base.pixels.view(np.uint64)), (opts, locked)
+            assert np.array_equal(rgb8, base.rgb8), (opts, locked)
+            rgb8[:] = 7
+            h.render_into(10, seeds, None, None, rgb8)
+            assert np.array_equal(rgb8, base.rgb8), (opts, locked)
+
+
 def test_render_is_deterministic_and_depth_zero_has_no_secondary_rays():
     g, o = pair("scenes/chapter11.yaml", 0.3)
     a, _ = g.render(7, None)
