@@ -200,6 +200,20 @@ int rt_render(rt_scene *scene, const rt_camera *camera, uint32_t depth, const ui
               rt_stats *stats);
 
 /*
+ * The same frame over n GPUs from one process: scenes[k] is a replica of the
+ * world created on GPU k (rt_init(k), then rt_scene_create) and renders the
+ * row blocks b with b % n == k, b = y / block_rows, side by side with the
+ * others (the fan-out of src/camera.rs:166-179 over devices); every block is
+ * then copied to its rows of the caller's frame, which is the whole Canvas
+ * (height*width*3) in host memory or, with out_on_device, on scenes[0]'s GPU.
+ * block_rows: a multiple of 8.  stats: n entries, or NULL.  Scenes may share a
+ * GPU (they then take turns).  Nothing is exchanged while tracing.
+ */
+int rt_render_multi(rt_scene *const *scenes, uint32_t n, const rt_camera *camera, uint32_t depth,
+                    const uint64_t *row_seeds, uint32_t block_rows, double *out_rgb, uint8_t *out_rgb8,
+                    int out_on_device, rt_stats *stats);
+
+/*
  * Page-locked host memory for the outputs of rt_render (the pixels of a Canvas,
  * src/canvas.rs:7-11): the device writes finished chunks straight into it, with
  * no staging copy.  No counterpart in the reference.

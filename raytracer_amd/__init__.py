@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "rt_init", "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_colour_at", "rt_probe",
     "rt_max_csg_list", "rt_max_container_list", "rt_last_error", "rt_set_option",
     "rt_colour_at_noalloc", "rt_noalloc_max_rays", "rt_lighting", "rt_intensity_at",
-    "rt_host_alloc", "rt_host_free",
+    "rt_host_alloc", "rt_host_free", "rt_render_multi",
 )
 OPT_STREAMS, OPT_CHUNK_PIXELS, OPT_RECS_PER_PIXEL, OPT_GRID_BLOCKS, OPT_TRAVERSAL, OPT_MIN_CHUNKS, OPT_PIN_OUTPUTS = 1, 2, 3, 4, 5, 6, 7
 HOST_ABI_SYMBOLS = (
@@ -112,6 +112,8 @@ def hip_lib():
         L.rt_set_option.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.rt_colour_at_noalloc.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.rt_noalloc_max_rays.restype = C.c_uint32
+        L.rt_render_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_void_p]
         L.rt_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.rt_host_free.argtypes = [C.c_void_p]
         _hip = L
@@ -190,6 +192,20 @@ def host_empty(shape, dtype):
     buf = (C.c_ubyte * max(1, n)).from_address(block.ptr.value)
     buf._owner = block
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def render_multi(scenes, depth, row_seeds, block_rows=8, rgb=None, rgb8=None, on_device=False):
+    """rt_render_multi: one frame over several uploaded replicas of a scene (normally one per GPU), assembled into
+    `rgb` / `rgb8` (numpy arrays of the whole frame, or raw device pointers with on_device).  Returns one stats
+    dict per replica."""
+    handles = (C.c_void_p * len(scenes))(*[s.upload() for s in scenes])
+    stats = (Stats * len(scenes))()
+    as_ptr = (lambda a: a) if on_device else _ptr
+    rc = hip_lib().rt_render_multi(handles, len(scenes), scenes[0].camera_ptr(), depth, _ptr(row_seeds), block_rows,
+                                   as_ptr(rgb), as_ptr(rgb8), 1 if on_device else 0, stats)
+    if rc != RT_OK:
+        raise RtError(rc, hip_lib().rt_last_error().decode())
+    return [st.as_dict() for st in stats]
 
 
 def init(device=0):

@@ -3713,6 +3713,92 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     return RT_OK;
 }
 
+// One frame over several scenes at once, each a replica of the same world on a GPU of its own: scene k renders
+// the row blocks b with b % n == k into its own device buffers, and the blocks are then copied to their places
+// in the caller's frame (one strided copy per scene and output).  Scenes on different devices run side by side,
+// one host thread per device; scenes that share a device take turns.
+int rt_render_multi(rt_scene* const* scenes, uint32_t n, const rt_camera* cam, uint32_t depth, const uint64_t* row_seeds,
+                    uint32_t block_rows, double* out_rgb, uint8_t* out_rgb8, int out_on_device, rt_stats* stats) {
+    if (!scenes || !cam || n == 0) return fail(RT_ERR_INVALID, "null argument");
+    for (uint32_t k = 0; k < n; k++) if (!scenes[k]) return fail(RT_ERR_INVALID, "null scene");
+    if (cam->width == 0 || cam->height == 0) return fail(RT_ERR_INVALID, "empty image");
+    if (block_rows == 0 || block_rows % 8 != 0) return fail(RT_ERR_INVALID, "block_rows must be a multiple of 8");
+    if (n == 1) return rt_render(scenes[0], cam, depth, row_seeds, nullptr, out_rgb, out_rgb8, out_on_device, stats);
+    for (uint32_t k = 0; k < n; k++)
+        for (uint32_t j = 0; j < k; j++)
+            if (scenes[j] == scenes[k]) return fail(RT_ERR_INVALID, "every rank needs a scene of its own");
+    const uint32_t W = cam->width, H = cam->height;
+    const uint32_t n_blocks = (H + block_rows - 1) / block_rows;
+    const int frame_device = scenes[0]->device;  // device outputs live on the first scene's GPU
+
+    auto render_one = [&](uint32_t k, std::string& error) -> int {
+        rt_scene* s = scenes[k];
+        const rt_partition part{block_rows, k, n};
+        int rc = hipSetDevice(s->device) == hipSuccess ? RT_OK : fail(RT_ERR_HIP, "hipSetDevice failed");
+        const size_t px = (size_t)local_rows(cam, &part) * W;
+        if (rc == RT_OK && px == 0) {
+            if (stats) std::memset(&stats[k], 0, sizeof stats[k]);
+            return RT_OK;
+        }
+        auto grow_stage = [&]() -> int {
+            if (s->stage_pixels >= px) return RT_OK;
+            if (s->stage_rgb) HIP_TRY(hipFree(s->stage_rgb));
+            if (s->stage_rgb8) HIP_TRY(hipFree(s->stage_rgb8));
+            s->stage_rgb = nullptr; s->stage_rgb8 = nullptr; s->stage_pixels = 0;
+            HIP_TRY(hipMalloc((void**)&s->stage_rgb, px * 3 * sizeof(double)));
+            HIP_TRY(hipMalloc((void**)&s->stage_rgb8, px * 3));
+            s->stage_pixels = px;
+            return RT_OK;
+        };
+        if (rc == RT_OK) rc = grow_stage();
+        if (rc == RT_OK)
+            rc = rt_render(s, cam, depth, row_seeds, &part, out_rgb ? s->stage_rgb : nullptr, out_rgb8 ? s->stage_rgb8 : nullptr, 1,
+                           stats ? &stats[k] : nullptr);
+        // this scene's blocks to their rows of the frame: local block j is global block k + j * n
+        auto place = [&](unsigned char* dst, const unsigned char* src, size_t bytes_per_px) -> int {
+            const size_t block_bytes = (size_t)block_rows * W * bytes_per_px;
+            const uint32_t mine = (n_blocks + n - 1 - k) / n;                     // blocks of this rank
+            const bool ragged = H % block_rows != 0 && (n_blocks - 1) % n == k;   // the frame's short last block is among them
+            const uint32_t whole = ragged ? mine - 1 : mine;
+            if (whole)
+                HIP_TRY(hipMemcpy2D(dst + (size_t)k * block_bytes, (size_t)n * block_bytes, src, block_bytes, block_bytes, whole,
+                                    hipMemcpyDefault));
+            if (ragged)
+                HIP_TRY(hipMemcpy(dst + (size_t)(n_blocks - 1) * block_bytes, src + (size_t)whole * block_bytes,
+                                  (size_t)(H % block_rows) * W * bytes_per_px, hipMemcpyDefault));
+            return RT_OK;
+        };
+        if (rc == RT_OK && out_rgb) rc = place((unsigned char*)out_rgb, (const unsigned char*)s->stage_rgb, 3 * sizeof(double));
+        if (rc == RT_OK && out_rgb8) rc = place(out_rgb8, s->stage_rgb8, 3);
+        if (rc != RT_OK) error = g_error;
+        return rc;
+    };
+
+    if (out_on_device)  // let the other GPUs write into the frame's GPU where the hardware links them
+        for (uint32_t k = 1; k < n; k++)
+            if (scenes[k]->device != frame_device && hipSetDevice(scenes[k]->device) == hipSuccess) {
+                (void)hipDeviceEnablePeerAccess(frame_device, 0);
+                (void)hipGetLastError();
+            }
+    std::vector<int> rcs(n, RT_OK);
+    std::vector<std::string> errors(n);
+    std::vector<int> devices;
+    for (uint32_t k = 0; k < n; k++)
+        if (std::find(devices.begin(), devices.end(), scenes[k]->device) == devices.end()) devices.push_back(scenes[k]->device);
+    auto run_device = [&](int device) {
+        for (uint32_t k = 0; k < n; k++)
+            if (scenes[k]->device == device) rcs[k] = render_one(k, errors[k]);
+    };
+    std::vector<std::thread> pool;
+    for (size_t d = 1; d < devices.size(); d++) pool.emplace_back(run_device, devices[d]);
+    run_device(devices[0]);
+    for (auto& t : pool) t.join();
+    (void)hipSetDevice(frame_device);
+    for (uint32_t k = 0; k < n; k++)
+        if (rcs[k] != RT_OK) return fail(rcs[k], "rank " + std::to_string(k) + ": " + errors[k]);
+    return RT_OK;
+}
+
 int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, const uint64_t* seeds, double* out_rgb) {
     if (!s || (n && (!rays || !out_rgb))) return fail(RT_ERR_INVALID, "null argument");
     if (n == 0) return RT_OK;

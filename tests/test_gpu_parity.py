@@ -89,6 +89,35 @@ def test_row_partition_renders_the_same_pixels():
         assert np.array_equal(frame.view(np.uint64), whole.pixels.view(np.uint64))
 
 
+@pytest.mark.parametrize("scene,scale,depth", [("scenes/chapter11.yaml", 0.3, 12), ("scenes/area-light.yaml", 0.25, 5),
+                                               ("scenes/chapter11.yaml", 0.37, 5)])
+def test_render_multi_assembles_the_frame_behind_the_c_abi(scene, scale, depth):
+    """rt_render_multi with 2, 3 and 5 replicas (all on this one GPU): the assembled Canvas equals the single
+    render bit for bit, in host memory and in device memory, and the replicas' ray counts add up."""
+    import torch
+    g, _ = pair(scene, scale)
+    seeds = g.row_seeds()
+    whole, st = g.render(depth, seeds)
+    for world, block_rows in ((2, 8), (3, 8), (5, 16)):
+        replicas = [pair(scene, scale)[0] for _ in range(world)]
+        rgb, rgb8 = np.full(whole.pixels.shape, -1.0), np.full(whole.pixels.shape, 9, dtype=np.uint8)
+        stats = ra.render_multi(replicas, depth, seeds, block_rows, rgb, rgb8)
+        assert np.array_equal(rgb.view(np.uint64), whole.pixels.view(np.uint64)), world
+        assert np.array_equal(rgb8, whole.rgb8), world
+        for key in ("primary_rays", "secondary_rays", "shadow_rays", "shade_hits"):
+            assert sum(s[key] for s in stats) == st[key], (world, key)
+        d8 = torch.full(whole.pixels.shape, 9, dtype=torch.uint8, device="cuda")
+        d64 = torch.full(whole.pixels.shape, -1.0, dtype=torch.float64, device="cuda")
+        ra.render_multi(replicas, depth, seeds, block_rows, d64.data_ptr(), d8.data_ptr(), on_device=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(d8.cpu().numpy(), whole.rgb8), world
+        assert np.array_equal(d64.cpu().numpy().view(np.uint64), whole.pixels.view(np.uint64)), world
+    with pytest.raises(ra.RtError):
+        ra.render_multi([g, g], depth, seeds, 8, rgb, rgb8)
+    with pytest.raises(ra.RtError):
+        ra.render_multi(replicas, depth, seeds, 12, rgb, rgb8)
+
+
 def test_host_outputs_arrive_whole_whatever_the_buffer():
     """Host outputs are filled chunk by chunk while later chunks render when the buffer is page-locked (by the
     caller, or by rt_render for the call) and by one pageable copy otherwise: the same bytes every way, also
