@@ -21,7 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HIP_LIB = os.path.join(_HERE, "librt_hip.so")
-HOST_LIB = os.path.join(_HERE, "librt_host.so")
+HOST_LIB = os.environ.get("RT_HOST_LIB", os.path.join(_HERE, "librt_host.so"))  # the variable selects a sanitizer build
 
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_UNSUPPORTED, RT_ERR_CAPACITY, RT_ERR_NAN = -1, -2, -3, -4, -5
