@@ -164,6 +164,8 @@ typedef struct rt_stats {
     uint64_t mesh_nodes;     /* nodes of the meshes' own hierarchies visited (128 bytes
                                 fetched each) and triangles tested in their leaves  */
     uint64_t mesh_tris;      /* (80 bytes each), by all rays of the frame           */
+    uint64_t big_chunks;     /* chunks rendered a second time with per-ray lists in
+                                global memory, after a fixed-size list overflowed    */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;
@@ -309,7 +311,16 @@ enum { RT_OPT_STREAMS = 1, RT_OPT_CHUNK_PIXELS = 2, RT_OPT_RECS_PER_PIXEL = 3, R
        RT_OPT_TRAVERSAL = 5, RT_OPT_MIN_CHUNKS = 6, RT_OPT_PIN_OUTPUTS = 7 };
 int rt_set_option(rt_scene *scene, int option, uint64_t value);
 
-/* Limits of this build (per-ray list bounds). */
+/*
+ * Limits of this build (per-ray list bounds).  The reference's lists are
+ * unbounded Vecs (src/object/csg/mod.rs:88-106, src/intersection/mod.rs:62-94).
+ * Here a ray keeps 32 entries of each list in fast memory; rt_render and
+ * rt_colour_at render a chunk in which some ray needs more a second time with
+ * kernels that keep the lists in global memory (rt_stats.big_chunks counts
+ * them), up to the numbers below and 64 nested csgs; past those the call fails
+ * with RT_ERR_CAPACITY.  rt_probe and rt_colour_at_noalloc have the fast lists
+ * only.
+ */
 uint32_t rt_max_csg_list(void);       /* intersections inside one outermost csg    */
 uint32_t rt_max_container_list(void); /* intersections at or before a refractive hit */
 

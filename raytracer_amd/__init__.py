@@ -61,7 +61,7 @@ class Stats(C.Structure):
         ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shadow", C.c_double), ("ms_shade", C.c_double),
         ("trace_launches", C.c_uint64), ("flop_trace", C.c_uint64),
         ("flop_shadow", C.c_uint64), ("flop_light", C.c_uint64), ("fused_shadows", C.c_uint64),
-        ("mesh_nodes", C.c_uint64), ("mesh_tris", C.c_uint64),
+        ("mesh_nodes", C.c_uint64), ("mesh_tris", C.c_uint64), ("big_chunks", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -61,7 +61,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int CSG_CAP = 32;        // intersections buffered inside one outermost csg
 constexpr int CSG_DEPTH = 6;       // nested csg levels
 constexpr int CONT_CAP = 32;       // intersections at or before a refractive hit
-constexpr int PAT_DEPTH = 6;       // nested pattern levels
+constexpr int PAT_DEPTH = 16;      // nested pattern levels
 constexpr int WAVE = 64;
 constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one step are sorted into (power of two, <= 64)
 #ifndef TRACE_WAVES
@@ -176,7 +176,14 @@ struct DevScene {
     const double* bvh;          // 16 f64 per inner node of the mesh hierarchies (see mesh_walk)
     const double* bvh_tris;     // 10 f64 per triangle of the hierarchies' leaves: p1, e1, e2, unit position (low word)
     const uint32_t* parent;     // n_units: unit position of the enclosing group / csg, NONE at the top
+    // The "big list" kernels only (a chunk whose per-ray lists overflowed the fixed ones is rendered again
+    // with them): per thread, big_csg_cap entries of a csg list and big_cont_cap of a candidate list.
+    double* big_ct; uint32_t* big_cl; double* big_cont_t; uint32_t *big_cont_pos, *big_cont_cls;
+    uint32_t big_csg_cap, big_cont_cap;
 };
+constexpr int BIG_CSG_DEPTH = 64;          // nested csg levels of the big-list kernels
+constexpr uint32_t BIG_LIST_MAX = 4096;    // entries per thread and list they are given at most
+constexpr uint32_t BIG_GRID = 256;         // their blocks (of 256 threads): the lists are per thread
 
 // Algorithmic FLOP constants (f64 add/sub/mul/div/sqrt/compare in the
 // reference's formulas); the device sums them per lane actually tested.
@@ -878,16 +885,25 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
 // (meshes): each lane follows its own path through the skip links, loading nodes with vector
 // loads, so a lane only pays for the boxes and leaves its own ray reaches.  Lanes at different
 // kinds of node take turns within an iteration.
-template <bool HAS_CSG, bool CULL, class Buf>
+template <bool HAS_CSG, bool CULL, bool BIG, class Buf>
 DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                        bool count, uint32_t& err) {
     const uint32_t n = S.n_units;
-    double ct[HAS_CSG ? CSG_CAP : 1];
-    uint32_t cl[HAS_CSG ? CSG_CAP : 1];
-    uint32_t cs_end[HAS_CSG ? CSG_DEPTH : 1], cs_csg[HAS_CSG ? CSG_DEPTH : 1];
-    int cs_start[HAS_CSG ? CSG_DEPTH : 1];
+    // the csg lists: fixed and lane-private, or (BIG) this thread's slice of the launch's global lists
+    constexpr int DEPTH = BIG ? BIG_CSG_DEPTH : CSG_DEPTH;
+    double ct_own[HAS_CSG && !BIG ? CSG_CAP : 1];
+    uint32_t cl_own[HAS_CSG && !BIG ? CSG_CAP : 1];
+    double* ct = ct_own;
+    uint32_t* cl = cl_own;
+    int csg_cap = CSG_CAP;
+    if constexpr (BIG) {
+        const size_t slice = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * S.big_csg_cap;
+        ct = S.big_ct + slice; cl = S.big_cl + slice; csg_cap = (int)S.big_csg_cap;
+    }
+    uint32_t cs_end[HAS_CSG ? DEPTH : 1], cs_csg[HAS_CSG ? DEPTH : 1];
+    int cs_start[HAS_CSG ? DEPTH : 1];
     int clen = 0, cs_top = 0;
-    (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top;
+    (void)ct; (void)cl; (void)cs_end; (void)cs_csg; (void)cs_start; (void)clen; (void)cs_top; (void)csg_cap;
     auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t lmat) {
         if constexpr (!Buf::enabled) {
             // a filtered shadow walk: the other kind of leaf does not exist; a walk that starts from
@@ -960,7 +976,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
             }
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && hit) {
-                    if (cs_top < CSG_DEPTH) {
+                    if (cs_top < DEPTH) {
                         cs_end[cs_top] = w1; cs_csg[cs_top] = w2; cs_start[cs_top] = clen;
                         cs_top++;
                     } else {
@@ -1010,7 +1026,7 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
                     bool on = k < h.n;
                     if constexpr (HAS_CSG) {
                         if (on && cs_top > 0) {
-                            if (clen < CSG_CAP) { ct[clen] = h.t[k]; cl[clen] = i; clen++; } else err |= 2u;
+                            if (clen < csg_cap) { ct[clen] = h.t[k]; cl[clen] = i; clen++; } else err |= 2u;
                             on = false;
                         }
                     }
@@ -1024,10 +1040,11 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
 
 // Chooses the walk: small trees are walked by the wave together (scalar loads, no divergence),
 // large ones lane by lane.
-template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf>
+template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf, bool BIG = false>
 DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                    bool count, uint32_t& err) {
-    if constexpr (PER_LANE) traverse_lane<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
+    static_assert(!BIG || PER_LANE, "the big-list kernels walk lane by lane");
+    if constexpr (PER_LANE) traverse_lane<HAS_CSG, CULL, BIG>(S, ray, lane_on, record, w, cb, flops, count, err);
     else traverse<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
 }
 
@@ -1485,7 +1502,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // Lightable::intensity_at of one shade point for every light (light/point.rs:27-38,
 // light/area.rs:75-90): one closest-hit shadow ray per light sample (World::is_shadowed,
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
-template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
                      Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE) {
     if (__ballot(on) == 0ull) return;
@@ -1519,13 +1536,13 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             Walk w = CULL ? walk_init_below(distance) : walk_init();
             if (__ballot(cast) != 0ull) {
                 if (CULL && PER_LANE && (S.flags & 4u)) {
-                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{false, 1u}, flops, true, err);
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{false, 1u}, flops, true, err);
                     bool nan_seen = w.nan_seen && w.arrival >= 2;
                     w.nan_seen = false; w.arrival = 0;
-                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{true, 2u}, flops, true, err);
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{true, 2u}, flops, true, err);
                     if (nan_seen) err |= 4u;
                 } else {
-                    walk_tree<HAS_CSG, CULL, PER_LANE>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0, 0u}, flops, true, err);
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0, 0u}, flops, true, err);
                 }
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
             }
@@ -1622,7 +1639,7 @@ DEV V3 combine(V3 surface, V3 reflected, V3 refracted, double m_reflective, doub
 // per-wave atomics would), and inside the block's range the children are grouped by (object they
 // start on, reflected / refracted), so that the next level's waves hold rays that meet the same
 // objects and a test culled for one lane is more often culled for all 64.
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true>
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true, bool BIG = false>
 __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -1640,11 +1657,19 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     const LevelState lv = A.levels[A.level];
     const uint32_t n_rays = lv.n, rec_base = lv.base, next_rec_base = lv.base + lv.n;
     if (blockIdx.x == 0 && threadIdx.x == 0) A.levels[A.level + 1].base = next_rec_base;
-    double big_t[CONT_CAP];
-    uint32_t big_pos[CONT_CAP], big_cls[CONT_CAP];
+    double big_t_own[BIG ? 1 : CONT_CAP];
+    uint32_t big_pos_own[BIG ? 1 : CONT_CAP], big_cls_own[BIG ? 1 : CONT_CAP];
+    double* big_t = big_t_own;
+    uint32_t *big_pos = big_pos_own, *big_cls = big_cls_own;
+    int cont_cap = CONT_CAP;
+    if constexpr (BIG) {  // this thread's slice of the launch's global candidate lists
+        const size_t slice = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * S.big_cont_cap;
+        big_t = S.big_cont_t + slice; big_pos = S.big_cont_pos + slice; big_cls = S.big_cont_cls + slice;
+        cont_cap = (int)S.big_cont_cap;
+    }
     RecordBuf buf;
     buf.fast = {s_rec_t, s_rec_pos, s_rec_cls, TRACE_BLOCK, REC_CAP, threadIdx.x};  // block-wide bases, this lane's column
-    buf.big = {big_t, big_pos, big_cls, 1, CONT_CAP, 0u};
+    buf.big = {big_t, big_pos, big_cls, 1, cont_cap, 0u};
     const bool record = (S.flags & 1u) != 0;  // scenes with a transparent material
     Work flops{}, flops_shadow{};
     uint32_t err = 0, n_shade = 0, n_spawned = 0, n_shadow = 0;
@@ -1712,7 +1737,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    walk_tree<HAS_CSG, CULL, PER_LANE>(S, ray, on, record, w, buf, flops, true, err);
+    walk_tree<HAS_CSG, CULL, PER_LANE, RecordBuf, BIG>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -1828,7 +1853,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     if constexpr (FUSED) {
         Rng none;
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE, CULL>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
+        intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
     }
     n_spawned += (uint32_t)__popcll(__ballot(spawn_refl)) + (uint32_t)__popcll(__ballot(spawn_refr));
     n_shade += (uint32_t)__popcll(__ballot(hit));
@@ -1874,7 +1899,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
 
 // The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
 // whole chunk first (area lights); otherwise k_trace casts them itself.
-template <bool HAS_CSG, bool PER_LANE, bool CULL = true>
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false>
 __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
@@ -1900,8 +1925,8 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states && on) rng = A.rng_states[A.R.order()[rec_idx]];
         const V3 normal = mk(A.R.nx()[rec_idx], A.R.ny()[rec_idx], A.R.nz()[rec_idx]);
-        if (per_light) intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
-        else intensities<HAS_CSG, PER_LANE, CULL>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
+        if (per_light) intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
+        else intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     const unsigned long long f_shadow = flops.flops + wave_sum_u32(flops.lane_flops);
     unsigned long long any_err = __ballot(err != 0);
@@ -2675,6 +2700,10 @@ struct Workspace {
     size_t pixel_base_cap = 0;
     uint32_t *row_total = nullptr, *row_base = nullptr;
     size_t row_cap = 0, row_base_cap = 0;
+    // the big-list kernels' per-thread lists (allocated when a chunk first overflows the fixed ones)
+    void* big_slab = nullptr;
+    size_t big_bytes = 0;
+    uint32_t big_csg_cap = 0, big_cont_cap = 0;
 };
 constexpr int MAX_STREAMS = 4;
 constexpr uint32_t RT_NOALLOC_MAX_RAYS = 1u << 16, RT_NOALLOC_MAX_DEPTH = 1022;  // limits of rt_colour_at_noalloc
@@ -2706,6 +2735,8 @@ struct rt_scene {
     unsigned long long* seeds = nullptr;
     size_t seeds_cap = 0;
     std::vector<uint32_t> leaf_unit;    // unit position of every leaf's record (rt_lighting takes leaf indices)
+    // the most intersections one ray can leave in the list of an outermost csg / in the world's list
+    uint64_t csg_list_bound = 0, world_list_bound = 0;
 };
 
 namespace {
@@ -2746,11 +2777,38 @@ int ensure_workspace(rt_scene* s, Workspace& w, size_t chunk_px, size_t n_first,
 void free_workspace(Workspace& w) {
     if (w.stream) (void)hipStreamSynchronize(w.stream);
     void* bufs[] = {w.rec_slab, w.intensity, w.levels, w.counters, w.stats, w.status,
-                    w.rng_states, w.pixel_base, w.row_total, w.row_base};
+                    w.rng_states, w.pixel_base, w.row_total, w.row_base, w.big_slab};
     for (void* p : bufs) if (p) (void)hipFree(p);
     for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace{};
+}
+
+// The lists of the big-list kernels: BIG_GRID x 256 threads, each with room for what the scene can produce at
+// most (up to BIG_LIST_MAX entries a list).
+int ensure_big(rt_scene* s, Workspace& w) {
+    const uint32_t csg_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s->csg_list_bound, 1), BIG_LIST_MAX);
+    const uint32_t cont_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(s->world_list_bound, CONT_CAP), BIG_LIST_MAX);
+    const size_t threads = (size_t)BIG_GRID * 256;
+    const size_t bytes = threads * ((size_t)csg_cap * 12 + (size_t)cont_cap * 16);
+    if (w.big_slab && w.big_bytes >= bytes && w.big_csg_cap == csg_cap && w.big_cont_cap == cont_cap) return RT_OK;
+    if (w.big_slab) { HIP_TRY(hipStreamSynchronize(w.stream)); HIP_TRY(hipFree(w.big_slab)); }
+    w.big_slab = nullptr; w.big_bytes = 0;
+    HIP_TRY(hipMalloc(&w.big_slab, bytes));
+    w.big_bytes = bytes; w.big_csg_cap = csg_cap; w.big_cont_cap = cont_cap;
+    return RT_OK;
+}
+DevScene big_scene(const rt_scene* s, const Workspace& w) {
+    DevScene d = s->dev;
+    const size_t threads = (size_t)BIG_GRID * 256;
+    unsigned char* p = (unsigned char*)w.big_slab;
+    d.big_ct = (double*)p; p += threads * w.big_csg_cap * 8;
+    d.big_cont_t = (double*)p; p += threads * w.big_cont_cap * 8;
+    d.big_cl = (uint32_t*)p; p += threads * w.big_csg_cap * 4;
+    d.big_cont_pos = (uint32_t*)p; p += threads * w.big_cont_cap * 4;
+    d.big_cont_cls = (uint32_t*)p;
+    d.big_csg_cap = w.big_csg_cap; d.big_cont_cap = w.big_cont_cap;
+    return d;
 }
 
 struct RunTotals {
@@ -2803,8 +2861,15 @@ void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
 // on the host).  `slot` selects the workspace's ChunkStatus entry and event quadruple.
 template <bool HAS_CSG, bool PER_LANE>
 int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
-                uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
+                uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot, bool big) {
     hipStream_t st = w.stream;
+    // `big`: the chunk overflowed a fixed per-ray list; walk it lane by lane with the lists in global memory
+    DevScene big_dev{};
+    if (big) {
+        int rc = ensure_big(s, w);
+        if (rc != RT_OK) return rc;
+        big_dev = big_scene(s, w);
+    }
     const uint32_t n_levels = depth + 1;
     const dim3 grid(level_grid(s, false)), grid_trace(level_grid(s, true)), block(256);
     LevelArgs A = base;
@@ -2824,7 +2889,12 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     for (uint32_t level = 0; level < n_levels; level++) {
         A.level = level;
         A.depth_remaining = depth - level;
-        if (first.primary && level == 0)
+        if (big) {
+            if (first.primary && level == 0)
+                hipLaunchKernelGGL((k_trace<true, true, true, false, true, true>), dim3(BIG_GRID), dim3(TRACE_BLOCK), 0, st, big_dev, A);
+            else
+                hipLaunchKernelGGL((k_trace<false, true, true, false, true, true>), dim3(BIG_GRID), dim3(TRACE_BLOCK), 0, st, big_dev, A);
+        } else if (first.primary && level == 0)
             launch_trace<true, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
         else
             launch_trace<false, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
@@ -2884,8 +2954,12 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
     }
 
     bool shadows_queued = false;
+    if (big) {
+        hipLaunchKernelGGL((k_shadow<true, true, true, true>), dim3(BIG_GRID), block, 0, st, big_dev, A);
+        shadows_queued = true;
+    }
     if constexpr (HAS_CSG && !PER_LANE) {
-        if (reference_walk(s)) {
+        if (!shadows_queued && reference_walk(s)) {
             hipLaunchKernelGGL((k_shadow<true, false, false>), grid, block, 0, st, s->dev, A);
             shadows_queued = true;
         }
@@ -2906,15 +2980,16 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
 }
 
 int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
-                         double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot) {
+                         double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot, bool big = false) {
     const bool per_lane = uses_lane_walk(s);
-    if (reference_walk(s)) return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    if (big) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, true);
+    if (reference_walk(s)) return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
     if (s->has_csg) {
-        if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
-        return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+        if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+        return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
     }
-    if (per_lane) return queue_chunk<false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
-    return queue_chunk<false, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot);
+    if (per_lane) return queue_chunk<false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+    return queue_chunk<false, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
 }
 
 // Wait for a workspace's stream and fetch the status of its first `n_slots` chunks.
@@ -2942,10 +3017,15 @@ void add_stats(RunTotals& tot, const ChunkStatus& c) {
     tot.levels = std::max(tot.levels, c.levels);
 }
 
-int check_status(const ChunkStatus& c) {
+// `big`: the status of a chunk that ran with the big-list kernels
+int check_status(const ChunkStatus& c, bool big = false) {
+    if ((c.error & 2u) && big)
+        return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed even in global memory (" + std::to_string(BIG_LIST_MAX) +
+                                         " entries a list, " + std::to_string(BIG_CSG_DEPTH) + " nested csgs)");
     if (c.error & 2u)
-        return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed (csg list " + std::to_string(CSG_CAP) +
-                                         ", container list " + std::to_string(CONT_CAP) + ")");
+        return fail(RT_ERR_CAPACITY, "a per-ray intersection list overflowed (csg list " + std::to_string(CSG_CAP) + ", " +
+                                         std::to_string(CSG_DEPTH) + " nested csgs, container list " + std::to_string(CONT_CAP) +
+                                         "); this entry point has no slow path for it");
     if (c.error & 4u) return fail(RT_ERR_NAN, "NaN intersection distance (the reference panics while sorting)");
     return RT_OK;
 }
@@ -3020,8 +3100,8 @@ int upload_rays(Workspace& w, uint32_t n, const double* rays) {
 extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
-uint32_t rt_max_csg_list(void) { return CSG_CAP; }
-uint32_t rt_max_container_list(void) { return CONT_CAP; }
+uint32_t rt_max_csg_list(void) { return BIG_LIST_MAX; }
+uint32_t rt_max_container_list(void) { return BIG_LIST_MAX; }
 
 int rt_init(int device) {
     HIP_TRY(hipSetDevice(device));
@@ -3106,6 +3186,21 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                 open.push_back(i);
                 if (d->node_kind[i] == RT_NODE_CSG) open_csgs++;
             }
+        }
+    }
+    // ---- the longest lists one ray can produce: every leaf delivers at most as many intersections as its shape
+    // has (sphere, cube 2; cylinder, cone 4; plane, triangle 1); an outermost csg buffers those of its subtree
+    uint64_t csg_list_bound = 0, world_list_bound = 0;
+    {
+        uint64_t in_outermost = 0;
+        uint32_t outermost_end = 0;
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            if (d->node_kind[i] == RT_NODE_CSG && !in_csg[i]) { in_outermost = 0; outermost_end = d->node_skip[i]; }
+            if (d->node_kind[i] != RT_NODE_LEAF) continue;
+            const uint32_t shape = d->leaf_shape[d->node_arg[i]];
+            const uint64_t hits = shape == RT_SPHERE || shape == RT_CUBE ? 2 : shape == RT_CYLINDER || shape == RT_CONE ? 4 : 1;
+            world_list_bound += hits;
+            if (i < outermost_end) { in_outermost += hits; csg_list_bound = std::max(csg_list_bound, in_outermost); }
         }
     }
     // ---- bounding spheres of the bounded leaves, and the clusters: runs of three or more sibling
@@ -3334,6 +3429,8 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     auto* s = new rt_scene();
     (void)hipGetDevice(&s->device);
     s->has_csg = has_csg;
+    s->csg_list_bound = csg_list_bound;
+    s->world_list_bound = world_list_bound;
     s->has_area = has_area;
     s->leaf_unit.assign(d->n_leaves, 0);
     for (uint32_t i = 0; i < d->n_nodes; i++)
@@ -3550,6 +3647,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     }
     const size_t recs_per_pixel_before = s->recs_per_pixel;
     size_t copies = 0;
+    uint32_t big_chunks = 0;
 
     auto frame = [&]() -> int {
     // row chunks: multiples of 8 rows, at most chunk_pixels pixels.  Each pass queues every
@@ -3577,11 +3675,11 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     if (frame_px >= ((size_t)2 << 20)) n_chunks = std::max<size_t>(n_chunks, s->min_chunks);
     if (n_chunks > 1) n_chunks = (n_chunks + n_ws - 1) / n_ws * n_ws;
     uint32_t chunk_rows = std::max(8u, (uint32_t)(((rows + n_chunks - 1) / n_chunks + 7) & ~(size_t)7));
-    struct Job { uint32_t r0, nr; };
+    struct Job { uint32_t r0, nr; bool big; };  // big: rendered again with the lists in global memory
     struct Arrival { hipEvent_t copied; size_t at, n; };  // a chunk's outputs: first element and element count
     std::vector<Job> pending;
     std::vector<Arrival> arrivals;
-    for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0)});
+    for (uint32_t r0 = 0; r0 < rows; r0 += chunk_rows) pending.push_back({r0, std::min(chunk_rows, rows - r0), false});
     while (!pending.empty()) {
         copies = 0;
         std::vector<Job> queued[MAX_STREAMS];
@@ -3604,7 +3702,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
             A.half_width = cam->half_width; A.half_height = cam->half_height; A.pixel_size = cam->pixel_size;
             FirstLevel first{true, (uint32_t)((size_t)j.nr * W), W, j.nr, s->seeds};
             int rc = queue_chunk_dispatch(s, s->ws[k], A, first, depth, d_rgb, d_rgb8, (size_t)j.r0 * W,
-                                          queued[k].size(), tot);
+                                          queued[k].size(), tot, j.big);
             if (rc != RT_OK) return rc;
             queued[k].push_back(j);
             if (host_async) {
@@ -3648,12 +3746,17 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
                         pending.push_back(j);
                     } else {
                         uint32_t half = ((j.nr / 2) + 7) & ~7u;
-                        pending.push_back({j.r0, half});
-                        pending.push_back({j.r0 + half, j.nr - half});
+                        pending.push_back({j.r0, half, j.big});
+                        pending.push_back({j.r0 + half, j.nr - half, j.big});
                     }
                     continue;
                 }
-                rc = check_status(st[i]);
+                if ((st[i].error & 2u) && !j.big) {  // a fixed per-ray list overflowed: the slow path
+                    pending.push_back({j.r0, j.nr, true});
+                    big_chunks++;
+                    continue;
+                }
+                rc = check_status(st[i], j.big);
                 if (rc != RT_OK) return rc;
                 add_stats(tot, st[i]);
                 chunks++;
@@ -3709,6 +3812,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
         stats->mesh_nodes = tot.mesh_nodes;
         stats->mesh_tris = tot.mesh_tris;
         stats->fused_shadows = fused_shadows(s, uses_lane_walk(s)) ? 1 : 0;
+        stats->big_chunks = big_chunks;
     }
     return RT_OK;
 }
@@ -3815,12 +3919,13 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
     A.part_world = 1;
     RunTotals tot;
     int rc = RT_OK;
+    bool big = false;
     for (;;) {
         rc = ensure_workspace(s, w, 0, n, depth, 1);
         if (rc == RT_OK) rc = upload_rays(w, n, rays);
         if (rc != RT_OK) break;
         FirstLevel first{false, n, 1, n, s->seeds};
-        rc = queue_chunk_dispatch(s, w, A, first, depth, d_out, nullptr, 0, 0, tot);
+        rc = queue_chunk_dispatch(s, w, A, first, depth, d_out, nullptr, 0, 0, tot, big);
         if (rc != RT_OK) break;
         std::vector<ChunkStatus> st;
         rc = collect(w, 1, st, tot);
@@ -3830,7 +3935,8 @@ int rt_colour_at(rt_scene* s, uint32_t n, const double* rays, uint32_t depth, co
             s->recs_per_pixel *= 4;
             continue;
         }
-        rc = check_status(st[0]);
+        if ((st[0].error & 2u) && !big) { big = true; continue; }  // a fixed per-ray list overflowed: the slow path
+        rc = check_status(st[0], big);
         break;
     }
     if (rc == RT_OK) {

@@ -54,7 +54,7 @@ def test_scene_create_rejects_bad_input_before_touching_the_gpu():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(ra.Partition) == 12
     assert C.sizeof(ra.CameraDesc) == 8 + 12 * 8 + 3 * 8
-    assert C.sizeof(ra.Stats) == 4 * 8 + 8 + 4 * 8 + 7 * 8
+    assert C.sizeof(ra.Stats) == 4 * 8 + 8 + 4 * 8 + 8 * 8
 
 
 def test_loading_the_reference_fixture_scene():  # scene/mod.rs:309-340 (src/scene/tests/simple.yaml)
