@@ -299,8 +299,10 @@ int rt_probe(rt_scene *scene, uint32_t n, const double *rays, double *out);
  *                          wave walk the tree together; 2: every lane walks on
  *                          its own (large trees; meshes by a hierarchy of their
  *                          own); 3: the reference's walk, test for test, with none
- *                          of the device-only shortcuts (slow; what the other
- *                          three are checked against)
+ *                          of the device-only shortcuts (slow; what the others
+ *                          are checked against); 4: the wave together down to
+ *                          the meshes, every lane on its own inside them (trees
+ *                          that are small apart from their meshes)
  *   RT_OPT_MIN_CHUNKS      a frame of two megapixels or more is cut into at least
  *                          this many chunks (default 2)
  *   RT_OPT_PIN_OUTPUTS     1 (default): rt_render tries to page-lock ordinary host

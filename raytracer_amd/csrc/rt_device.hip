@@ -173,7 +173,7 @@ struct DevScene {
     const double* pat_col;      // n_patterns*4
     const double* light;        // n_lights*12
     const uint32_t* light_meta; // n_lights*4: kind, usteps, vsteps, 0
-    const double* bvh;          // 16 f64 per inner node of the mesh hierarchies (see mesh_walk)
+    const float* bvh;           // 32 words per inner node of the mesh hierarchies: four children's boxes and references (see mesh_walk)
     const double* bvh_tris;     // 10 f64 per triangle of the hierarchies' leaves: p1, e1, e2, unit position (low word)
     const uint32_t* parent;     // n_units: unit position of the enclosing group / csg, NONE at the top
     // The "big list" kernels only (a chunk whose per-ray lists overflowed the fixed ones is rendered again
@@ -546,7 +546,13 @@ DEV bool sphere_culled(const Ray& ray, V3 c, double r2, bool skip_behind, const 
 // object/csg/mod.rs:57-106).  `record` is wave-uniform.  With CULL the walk skips tests that cannot
 // change the closest hit or what sorts before it (w.arrival then no longer counts every
 // intersection of the reference's list; rt_probe, which reports that count, walks without it).
-template <bool HAS_CSG, bool CULL, class Buf>
+template <class Buf>
+DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, V3 mag, Walk& w,
+                   bool record, Buf cb, bool any_hit, Work& flops, bool count);
+
+// With HYBRID the wave walks the tree together down to the meshes and every lane walks a mesh its ray reaches on
+// its own, by the mesh's hierarchy (mesh_walk): for scenes whose tree is small once the meshes are set aside.
+template <bool HAS_CSG, bool CULL, bool HYBRID, class Buf>
 DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                   bool count, uint32_t& err) {
     uint32_t skip_until = lane_on ? 0u : NONE;
@@ -562,10 +568,14 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
 
     // `cls` is the structural-equality class of the leaf at unit position p.  Only the hit's distance
     // and position are tracked here; its header words are read back when the walk is over.
-    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls) {
+    auto emit = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0) {
+        if constexpr (HYBRID && !Buf::enabled) {  // a filtered shadow walk (see NoRecord)
+            if (cb.filter) on = on && (((lw0 >> 8) & 1u) != 0) == (cb.filter == 2u);
+        }
         if (on) {
             if (tt != tt) w.nan_seen = true;
-            const bool below = w.pos == NONE || tt < w.t;
+            bool below = w.pos == NONE || tt < w.t;
+            if constexpr (HYBRID && !Buf::enabled) below = below || (cb.filter == 2u && tt == w.t && p < w.pos && w.pos < LIMIT);
             if constexpr (Buf::enabled) {
                 if (record && below) {
                     if (w.n < cb.cap()) { cb.put(w.n, tt, p, cls); w.n++; } else w.overflow = true;
@@ -579,7 +589,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
     uint32_t i = 0;
     for (;;) {
         if constexpr (HAS_CSG) {
-            auto emit_csg = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t, uint32_t) { emit(on, tt, p, cls); };
+            auto emit_csg = [&](bool on, double tt, uint32_t p, uint32_t cls, uint32_t lw0, uint32_t) { emit(on, tt, p, cls, lw0); };
             close_csgs(S, i, ct, cl, cs_end, cs_csg, cs_start, clen, cs_top, err, emit_csg, Buf::enabled && record);
         }
         if (i >= n) break;
@@ -630,6 +640,25 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
             // (object/csg/mod.rs:117-121).
             if (CULL && kind == K_GROUP && (w0 & GROUP_SOUND) && hit && w.pos != NONE && t0 > w.t * (1.0 + CULL_REL) + CULL_ABS) hit = false;
             if (act && !hit) skip_until = end;
+            if constexpr (HYBRID && CULL) {
+                if (kind == K_GROUP && (w0 & MESH_BIT)) {  // meshes never lie inside a csg (rt_scene_create)
+                    bool skip_mesh = false, any_hit = false;
+                    if constexpr (!Buf::enabled) {
+                        skip_mesh = (cb.filter == 1u && (w0 & MESH_ALL_CAST)) || (cb.filter == 2u && (w0 & MESH_NONE_CAST));
+                        any_hit = cb.any_hit;
+                    }
+                    if (act && hit) {
+                        skip_until = end;
+                        if (!skip_mesh) {
+                            const V3 mag = mk(2.0 * fmax(fabs(q[2]), fabs(q[5])), 2.0 * fmax(fabs(q[3]), fabs(q[6])),
+                                              2.0 * fmax(fabs(q[4]), fabs(q[7])));
+                            const uint32_t pos_before = w.pos;
+                            mesh_walk(S, ray, i, w2, w3, mag, w, record, cb, any_hit, flops, count);
+                            if (any_hit && w.pos != pos_before && ((w.w0 >> 8) & 1u)) skip_until = NONE;  // settled
+                        }
+                    }
+                }
+            }
             if constexpr (HAS_CSG) {
                 if (kind == K_CSG && act && hit) {
                     if (cs_top < CSG_DEPTH) {
@@ -723,7 +752,7 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
                     on = false;
                 }
             }
-            emit(on, h.t[k], i, w3);
+            emit(on, h.t[k], i, w3, w0);
         }
         i += 2;
     }
@@ -736,8 +765,9 @@ DEV void traverse(const DevScene& S, const Ray& ray, bool lane_on, bool record, 
 
 // ---------------------------------------------------------------- meshes
 // A group whose subtree holds nothing but triangles under one matrix (an OBJ mesh, divided or not)
-// carries a second, device-only hierarchy over the same triangles: a binary tree built with the
-// surface-area heuristic in the mesh's object space, four triangles or fewer per leaf, walked
+// carries a second, device-only hierarchy over the same triangles: built with the surface-area
+// heuristic in the mesh's object space as a binary tree, four triangles or fewer per leaf, then
+// folded into nodes of up to four children whose boxes are kept in f32 (rounded outwards), and walked
 // nearest child first with a small stack.  The reference's own tree is whatever Group::divide
 // (object/group/mod.rs:50-139) made of the file's order - children that straddle a split stay in
 // the parent, the walk order is fixed - so a ray through it tests many times more boxes and
@@ -786,6 +816,12 @@ DEV bool mesh_ancestors_pass(const DevScene& S, const Ray& ray, double t, uint32
 }
 
 // One lane's ray against a mesh.  `ray` is the world-space ray.
+// An inner node has up to four children; their boxes are stored in f32, rounded outwards, and tested in f32
+// with every rounding of that arithmetic added back as slack (the boxes only have to be conservative; the
+// triangle tests stay the reference's, in f64).  With u = 2^-24: the computed slab distance
+// fl(fl(b - fl(o)) * fl(1/d)) differs from (b - o)/d by at most |o/d| * 1.01u + |t| * 3.1u, so every axis is
+// widened by e = |o/d| * 2u and the interval by 8u of its ends.  An axis whose terms come out NaN or
+// infinite (d = 0, o or 1/d beyond f32) drops out of the fmin / fmax chain and constrains nothing.
 template <class Buf>
 DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_t root_ref, uint32_t xf, V3 mag, Walk& w,
                    bool record, Buf cb, bool any_hit, Work& flops, bool count) {
@@ -797,76 +833,102 @@ DEV void mesh_walk(const DevScene& S, const Ray& ray, uint32_t root_pos, uint32_
     Ray r;
     r.o = mul_point_v(m, ray.o);
     r.d = mul_vector_v(m, ray.d);
-    const V3 inv = mk(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
+    constexpr float U2 = 1.1920929e-7f, U8 = 4.7683716e-7f;  // 2u, 8u
+    const float ox = (float)r.o.x, oy = (float)r.o.y, oz = (float)r.o.z;
+    const float ix = (float)(1.0 / r.d.x), iy = (float)(1.0 / r.d.y), iz = (float)(1.0 / r.d.z);
+    const float ex = fabsf(ox * ix) * U2, ey = fabsf(oy * iy) * U2, ez = fabsf(oz * iz) * U2;
     uint32_t stack[BVH_STACK];
-    double stack_t[BVH_STACK];
+    float stack_t[BVH_STACK];
     int sp = 0;
     uint32_t cur = root_ref;
     const double huge = __builtin_huge_val();
+    const float inf = __builtin_huge_valf();
+    // The lanes that walk this mesh together alternate between two phases, each a loop over one kind of work:
+    // down through inner nodes until every lane holds a leaf (or has run out), then through the leaves'
+    // triangles.  A lane that reaches its leaf early waits for the others; in exchange the wave never
+    // executes both kinds of step in the same iteration.
     for (;;) {
-        const double hi = w.pos == NONE ? huge : w.t * (1.0 + CULL_REL) + CULL_ABS;
-        if (cur == NONE) {
-            while (sp > 0) {
-                sp--;
-                if (!(stack_t[sp] > hi)) { cur = stack[sp]; break; }
-            }
-            if (cur == NONE) break;
-        }
-        if (cur & BVH_LEAF) {
-            const uint32_t at = cur & 0x07FFFFFFu, left = (cur >> 27) & 15u;
-            cur = left ? (BVH_LEAF | ((left - 1u) << 27) | (at + 1u)) : NONE;
-            const double* ld = S.bvh_tris + (size_t)at * 10;
-            double td[10];
-#pragma unroll
-            for (int k = 0; k < 10; k++) td[k] = ld[k];
-            const uint32_t pos = (uint32_t)__double2loint(td[9]);
-            double t, u, v;
-            const bool got = triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
-            if (count) { flops.add_lane(F_XFORM + F_TRI); flops.tris++; }
-            if (got) {
-                if (t != t) w.nan_seen = true;
-                w.arrival++;
-                const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
-                const uint32_t* lr = S.stream + (size_t)pos * 16;
-                const bool wanted = filter == 0 || (((lr[0] >> 8) & 1u) != 0) == (filter == 2u);
-                if ((t > 0.0 || rec) && below && wanted && mesh_ancestors_pass(S, ray, t, pos, root_pos, mag)) {
-                    if (rec) {
-                        if (w.n < cb.cap()) { cb.put(w.n, t, pos, lr[3]); w.n++; } else w.overflow = true;
-                    }
-                    if (t > 0.0) {
-                        w.t = t; w.pos = pos; w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
-                        if (any_hit) break;
-                    }
+        for (;;) {
+            const double hi = w.pos == NONE ? huge : w.t * (1.0 + CULL_REL) + CULL_ABS;
+            const float hi_f = (float)hi * (1.0f + U2) + 1e-30f;  // never below hi
+            if (cur == NONE) {
+                while (sp > 0) {
+                    sp--;
+                    if (!(stack_t[sp] > hi_f)) { cur = stack[sp]; break; }
                 }
             }
-        } else {
-            const double* nd = S.bvh + (size_t)cur * 16;
-            double b[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) b[k] = nd[k];
-            const uint32_t c0 = (uint32_t)__double2loint(nd[12]), c1 = (uint32_t)__double2hiint(nd[12]);
-            if (count) { flops.add_lane(2 * F_BOX); flops.nodes++; }
-            double near_[2];
-            bool hit_[2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const double ax = (b[c * 6 + 0] - r.o.x) * inv.x, bx = (b[c * 6 + 3] - r.o.x) * inv.x;
-                const double ay = (b[c * 6 + 1] - r.o.y) * inv.y, by = (b[c * 6 + 4] - r.o.y) * inv.y;
-                const double az = (b[c * 6 + 2] - r.o.z) * inv.z, bz = (b[c * 6 + 5] - r.o.z) * inv.z;
-                // fmin / fmax drop a NaN operand (0 * inf: the origin on the face of a slab the ray runs along)
-                const double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-                const double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
-                const double slack = 1e-12 * (fmin(fabs(tn), 1e300) + fmin(fabs(tf), 1e300)) + 1e-300;
-                near_[c] = tn;
-                hit_[c] = tn <= tf + slack && tn <= hi && (rec || tf + slack >= 0.0);
+            const bool inner = cur != NONE && !(cur & BVH_LEAF);
+            if (__ballot(inner) == 0ull) break;
+            if (inner) {
+                const float4* nd = (const float4*)(S.bvh + (size_t)cur * 32);
+                const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+                const uint4 refs = *(const uint4*)(nd + 6);
+                if (count) { flops.add_lane(4 * F_BOX); flops.nodes++; }
+                float key[4];
+                uint32_t ref[4];
+#define RT_CHILD(c, f)                                                                                             \
+                {                                                                                                  \
+                    const float ax = (lx.f - ox) * ix, bx = (hx.f - ox) * ix;                                      \
+                    const float ay = (ly.f - oy) * iy, by = (hy.f - oy) * iy;                                      \
+                    const float az = (lz.f - oz) * iz, bz = (hz.f - oz) * iz;                                      \
+                    const float tn = fmaxf(fmaxf(fminf(ax, bx) - ex, fminf(ay, by) - ey), fminf(az, bz) - ez);     \
+                    const float tf = fminf(fminf(fmaxf(ax, bx) + ex, fmaxf(ay, by) + ey), fmaxf(az, bz) + ez);     \
+                    const float slack = U8 * (fminf(fabsf(tn), 1e30f) + fminf(fabsf(tf), 1e30f)) + 1e-30f;         \
+                    const float lo_t = tn - slack, hi_t = tf + slack;                                              \
+                    const bool hit = refs.f != NONE && lo_t <= hi_t && lo_t <= hi_f && (rec || hi_t >= 0.0f);      \
+                    key[c] = hit ? lo_t : inf;                                                                     \
+                    ref[c] = hit ? refs.f : NONE;                                                                  \
+                }
+                RT_CHILD(0, x) RT_CHILD(1, y) RT_CHILD(2, z) RT_CHILD(3, w)
+#undef RT_CHILD
+                // nearest first: a five-exchange sorting network over (entry distance, child); misses sort last
+#define RT_SWAP(a, b)                                                                                              \
+                {                                                                                                  \
+                    const bool sw = key[b] < key[a];                                                               \
+                    const float ka = sw ? key[b] : key[a], kb = sw ? key[a] : key[b];                              \
+                    const uint32_t ra = sw ? ref[b] : ref[a], rb = sw ? ref[a] : ref[b];                           \
+                    key[a] = ka; key[b] = kb; ref[a] = ra; ref[b] = rb;                                            \
+                }
+                RT_SWAP(0, 1) RT_SWAP(2, 3) RT_SWAP(0, 2) RT_SWAP(1, 3) RT_SWAP(1, 2)
+#undef RT_SWAP
+                // the build keeps every hierarchy shallow enough for three entries a level
+                if (ref[3] != NONE && sp < BVH_STACK) { stack[sp] = ref[3]; stack_t[sp] = key[3]; sp++; }
+                if (ref[2] != NONE && sp < BVH_STACK) { stack[sp] = ref[2]; stack_t[sp] = key[2]; sp++; }
+                if (ref[1] != NONE && sp < BVH_STACK) { stack[sp] = ref[1]; stack_t[sp] = key[1]; sp++; }
+                cur = ref[0];
             }
-            if (hit_[0] && hit_[1]) {
-                const bool swap = near_[1] < near_[0];
-                const uint32_t first = swap ? c1 : c0, second = swap ? c0 : c1;
-                if (sp < BVH_STACK) { stack[sp] = second; stack_t[sp] = swap ? near_[0] : near_[1]; sp++; }
-                cur = first;
-            } else {
-                cur = hit_[0] ? c0 : (hit_[1] ? c1 : NONE);
+        }
+        if (__ballot(cur != NONE) == 0ull) break;  // every lane has run out of nodes
+        for (;;) {  // here `cur` is a leaf reference or NONE
+            const bool leaf = cur != NONE;
+            if (__ballot(leaf) == 0ull) break;
+            if (leaf) {
+                const uint32_t at = cur & 0x07FFFFFFu, left = (cur >> 27) & 15u;
+                cur = left ? (BVH_LEAF | ((left - 1u) << 27) | (at + 1u)) : NONE;
+                const double* ld = S.bvh_tris + (size_t)at * 10;
+                double td[10];
+#pragma unroll
+                for (int k = 0; k < 10; k++) td[k] = ld[k];
+                const uint32_t pos = (uint32_t)__double2loint(td[9]);
+                double t, u, v;
+                const bool got = triangle_hit(r, mk(td[0], td[1], td[2]), mk(td[3], td[4], td[5]), mk(td[6], td[7], td[8]), t, u, v);
+                if (count) { flops.add_lane(F_XFORM + F_TRI); flops.tris++; }
+                if (got) {
+                    if (t != t) w.nan_seen = true;
+                    w.arrival++;
+                    const bool below = w.pos == NONE || t < w.t || (t == w.t && pos < w.pos && w.pos < LIMIT);
+                    const uint32_t* lr = S.stream + (size_t)pos * 16;
+                    const bool wanted = filter == 0 || (((lr[0] >> 8) & 1u) != 0) == (filter == 2u);
+                    if ((t > 0.0 || rec) && below && wanted && mesh_ancestors_pass(S, ray, t, pos, root_pos, mag)) {
+                        if (rec) {
+                            if (w.n < cb.cap()) { cb.put(w.n, t, pos, lr[3]); w.n++; } else w.overflow = true;
+                        }
+                        if (t > 0.0) {
+                            w.t = t; w.pos = pos; w.w0 = lr[0]; w.mat = lr[1]; w.cls = lr[3];
+                            if (any_hit) { cur = NONE; sp = 0; }  // settled: this lane is done with the mesh
+                        }
+                    }
+                }
             }
         }
     }
@@ -1040,12 +1102,13 @@ DEV void traverse_lane(const DevScene& S, const Ray& ray, bool lane_on, bool rec
 
 // Chooses the walk: small trees are walked by the wave together (scalar loads, no divergence),
 // large ones lane by lane.
-template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf, bool BIG = false>
+template <bool HAS_CSG, bool CULL, bool PER_LANE, class Buf, bool BIG = false, bool HYBRID = false>
 DEV void walk_tree(const DevScene& S, const Ray& ray, bool lane_on, bool record, Walk& w, Buf cb, Work& flops,
                    bool count, uint32_t& err) {
     static_assert(!BIG || PER_LANE, "the big-list kernels walk lane by lane");
+    static_assert(!HYBRID || !PER_LANE, "the hybrid walk is the wave's walk with the meshes lane by lane");
     if constexpr (PER_LANE) traverse_lane<HAS_CSG, CULL, BIG>(S, ray, lane_on, record, w, cb, flops, count, err);
-    else traverse<HAS_CSG, CULL>(S, ray, lane_on, record, w, cb, flops, count, err);
+    else traverse<HAS_CSG, CULL, HYBRID>(S, ray, lane_on, record, w, cb, flops, count, err);
 }
 
 // ---------------------------------------------------------------- patterns
@@ -1502,7 +1565,7 @@ DEV void rng_skip(Rng& r, uint32_t draws) { for (uint32_t k = 0; k < draws; k++)
 // Lightable::intensity_at of one shade point for every light (light/point.rs:27-38,
 // light/area.rs:75-90): one closest-hit shadow ray per light sample (World::is_shadowed,
 // world.rs:109-126).  Called by all lanes of a wave; `on` marks the lanes that hold a shade point.
-template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false>
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false, bool HYBRID = false>
 DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t rec_idx, V3 over, V3 normal, Rng rng,
                      Work& flops, uint32_t& err, uint32_t& n_shadow, uint32_t l_begin = 0, uint32_t l_end = NONE) {
     if (__ballot(on) == 0ull) return;
@@ -1535,14 +1598,14 @@ DEV void intensities(const DevScene& S, const LevelArgs& A, bool on, uint32_t re
             const bool cast = on && !moot;
             Walk w = CULL ? walk_init_below(distance) : walk_init();
             if (__ballot(cast) != 0ull) {
-                if (CULL && PER_LANE && (S.flags & 4u)) {
-                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{false, 1u}, flops, true, err);
+                if (CULL && (PER_LANE || HYBRID) && (S.flags & 4u)) {
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG, HYBRID>(S, sr, cast, false, w, NoRecord{false, 1u}, flops, true, err);
                     bool nan_seen = w.nan_seen && w.arrival >= 2;
                     w.nan_seen = false; w.arrival = 0;
-                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{true, 2u}, flops, true, err);
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG, HYBRID>(S, sr, cast, false, w, NoRecord{true, 2u}, flops, true, err);
                     if (nan_seen) err |= 4u;
                 } else {
-                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0, 0u}, flops, true, err);
+                    walk_tree<HAS_CSG, CULL, PER_LANE, NoRecord, BIG, HYBRID>(S, sr, cast, false, w, NoRecord{CULL && (S.flags & 2u) != 0, 0u}, flops, true, err);
                 }
                 if (w.nan_seen && w.arrival >= 2) err |= 4u;
             }
@@ -1639,8 +1702,9 @@ DEV V3 combine(V3 surface, V3 reflected, V3 refracted, double m_reflective, doub
 // per-wave atomics would), and inside the block's range the children are grouped by (object they
 // start on, reflected / refracted), so that the next level's waves hold rays that meet the same
 // objects and a test culled for one lane is more often culled for all 64.
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true, bool BIG = false>
-__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true, bool BIG = false, bool HYBRID = false>
+__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : (PER_LANE || HYBRID) ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
+    constexpr bool LANES_DIVERGE = PER_LANE || HYBRID;  // walks of very different length side by side in one wave
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
     constexpr uint32_t WAVES = TRACE_BLOCK / 64;
@@ -1678,7 +1742,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     // power of two): lanes of one wave at different kinds of node take turns, so a wave's walk costs
     // the sum of its lanes' branches, and such a level lasts as long as its slowest wave.
     uint32_t lanes = 64;
-    if constexpr (PER_LANE && !PRIMARY) {
+    if constexpr (LANES_DIVERGE && !PRIMARY) {
 #ifndef SPREAD_WAVES
 #define SPREAD_WAVES 4096u
 #endif
@@ -1737,7 +1801,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     PHASE(1);
     Walk w = walk_init();
     // closest hit, recording what may sort before it
-    walk_tree<HAS_CSG, CULL, PER_LANE, RecordBuf, BIG>(S, ray, on, record, w, buf, flops, true, err);
+    walk_tree<HAS_CSG, CULL, PER_LANE, RecordBuf, BIG, HYBRID>(S, ray, on, record, w, buf, flops, true, err);
     PHASE(2);
     if (w.nan_seen && w.arrival >= 2) err |= 4u;
     const bool hit = on && w.pos != NONE;
@@ -1853,7 +1917,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     if constexpr (FUSED) {
         Rng none;
         none.s0 = none.s1 = none.s2 = none.s3 = 0;
-        intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
+        intensities<HAS_CSG, PER_LANE, CULL, BIG, HYBRID>(S, A, hit, rec_idx, over, normal, none, flops_shadow, err, n_shadow);
     }
     n_spawned += (uint32_t)__popcll(__ballot(spawn_refl)) + (uint32_t)__popcll(__ballot(spawn_refr));
     n_shade += (uint32_t)__popcll(__ballot(hit));
@@ -1872,7 +1936,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
     // statistics: one atomic per wave and counter (the counters are sums over the wave already)
     const unsigned long long f_trace = flops.flops + wave_sum_u32(flops.lane_flops);
     unsigned long long any_err = __ballot(err != 0);
-    if constexpr (PER_LANE) {
+    if constexpr (LANES_DIVERGE) {
         const uint32_t s_nodes = wave_sum_u32(flops.nodes + flops_shadow.nodes), s_tris = wave_sum_u32(flops.tris + flops_shadow.tris);
         if (lane == 0 && (s_nodes | s_tris)) {
             StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
@@ -1899,8 +1963,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : PER_LANE ? LANE_TRACE_WA
 
 // The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
 // whole chunk first (area lights); otherwise k_trace casts them itself.
-template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false>
-__global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
+template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false, bool HYBRID = false>
+__global__ __launch_bounds__(256, HAS_CSG ? 2 : (PER_LANE || HYBRID) ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
+    constexpr bool LANES_DIVERGE = PER_LANE || HYBRID;
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
     const uint32_t total = A.levels[A.n_levels].base;  // records of the whole chunk
@@ -1909,7 +1974,7 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
     // Without an area light a shade point's lights are independent (no rng stream runs through
     // them): a lane-walked tree takes one (block of records, light) pair per step, which shortens
     // each lane's chain of walks and multiplies the number of waves in flight.
-    const bool per_light = PER_LANE && !A.rng_states && S.n_lights > 1;
+    const bool per_light = LANES_DIVERGE && !A.rng_states && S.n_lights > 1;
     const unsigned long long n_blocks = (total + 255u) / 256u, n_steps = n_blocks * (per_light ? S.n_lights : 1u);
     for (unsigned long long step = blockIdx.x; step < n_steps; step += gridDim.x) {
         LOOP_FENCE();
@@ -1925,12 +1990,12 @@ __global__ __launch_bounds__(256, HAS_CSG ? 2 : PER_LANE ? LANE_SHADOW_WAVES : S
         rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
         if (A.rng_states && on) rng = A.rng_states[A.R.order()[rec_idx]];
         const V3 normal = mk(A.R.nx()[rec_idx], A.R.ny()[rec_idx], A.R.nz()[rec_idx]);
-        if (per_light) intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
-        else intensities<HAS_CSG, PER_LANE, CULL, BIG>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
+        if (per_light) intensities<HAS_CSG, PER_LANE, CULL, BIG, HYBRID>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow, light, light + 1u);
+        else intensities<HAS_CSG, PER_LANE, CULL, BIG, HYBRID>(S, A, on, rec_idx, over, normal, rng, flops, err, n_shadow);
     }
     const unsigned long long f_shadow = flops.flops + wave_sum_u32(flops.lane_flops);
     unsigned long long any_err = __ballot(err != 0);
-    if constexpr (PER_LANE) {
+    if constexpr (LANES_DIVERGE) {
         const uint32_t s_nodes = wave_sum_u32(flops.nodes), s_tris = wave_sum_u32(flops.tris);
         if (lane == 0 && (s_nodes | s_tris)) {
             StatShard* st = A.stats + (blockIdx.x % STAT_SHARDS);
@@ -2278,9 +2343,9 @@ __global__ __launch_bounds__(256) void k_probe(DevScene S, uint32_t n, Recs R, d
             jr.d = normalise(vec);
             jon = hit;
             w = walk_init();
-            traverse<HAS_CSG, true>(S, jr, jon, false, w, NoRecord{}, flops, false, err);
+            traverse<HAS_CSG, true, false>(S, jr, jon, false, w, NoRecord{}, flops, false, err);
         } else {
-            traverse<HAS_CSG, false>(S, jr, jon, true, w, buf, flops, false, err);
+            traverse<HAS_CSG, false, false>(S, jr, jon, true, w, buf, flops, false, err);
         }
         if (job == 0) {
             if (w.nan_seen && w.arrival >= 2) err |= 4u;
@@ -2551,8 +2616,12 @@ std::vector<unsigned long long> rng_jump_matrices(uint64_t draws) {
 
 // ---- the meshes' own hierarchies (see mesh_walk)
 struct MeshTri { double lo[3], hi[3], c[3]; uint32_t pos; };
-struct MeshBuild { std::vector<double> nodes; std::vector<double> tris; const uint32_t* stream; };
-constexpr uint32_t MESH_MIN_TRIS = 4, MESH_LEAF_TRIS = 4;
+struct BinNode { double lo[2][3], hi[2][3]; uint32_t c[2]; };  // a node of the binary tree the wide one is made from
+struct MeshBuild { std::vector<BinNode> bin; std::vector<float> nodes; std::vector<double> tris; const uint32_t* stream; };
+#ifndef MESH_LEAF_TRIS_N
+#define MESH_LEAF_TRIS_N 4
+#endif
+constexpr uint32_t MESH_MIN_TRIS = 4, MESH_LEAF_TRIS = MESH_LEAF_TRIS_N;
 
 void mesh_bounds(const MeshTri* t, size_t n, double* lo, double* hi) {
     for (int a = 0; a < 3; a++) { lo[a] = HUGE_VAL; hi[a] = -HUGE_VAL; }
@@ -2638,21 +2707,66 @@ uint32_t mesh_build(std::vector<MeshTri>& t, size_t b, size_t e, int depth, Mesh
         std::nth_element(t.begin() + b, t.begin() + mid, t.begin() + e,
                          [a](const MeshTri& x, const MeshTri& y) { return x.c[a] < y.c[a] || (x.c[a] == y.c[a] && x.pos < y.pos); });
     }
-    const size_t node = out.nodes.size() / 16;
-    out.nodes.resize(out.nodes.size() + 16, 0.0);
+    const size_t node = out.bin.size();
+    out.bin.emplace_back();
     const uint32_t c0 = mesh_build(t, b, mid, depth + 1, out), c1 = mesh_build(t, mid, e, depth + 1, out);
-    double* nd = &out.nodes[node * 16];
+    BinNode& nd = out.bin[node];
     for (int c = 0; c < 2; c++) {
         double lo[3], hi[3];
         mesh_bounds(&t[c ? mid : b], c ? e - mid : mid - b, lo, hi);
         for (int q = 0; q < 3; q++) {
             const double pad = 1e-9 * std::max(std::max(std::fabs(lo[q]), std::fabs(hi[q])), hi[q] - lo[q]) + 1e-30;
-            nd[c * 6 + q] = lo[q] - pad;
-            nd[c * 6 + 3 + q] = hi[q] + pad;
+            nd.lo[c][q] = lo[q] - pad;
+            nd.hi[c][q] = hi[q] + pad;
         }
     }
-    uint32_t refs[2] = {c0, c1};
-    std::memcpy(&nd[12], refs, 8);
+    nd.c[0] = c0; nd.c[1] = c1;
+    return (uint32_t)node;
+}
+
+// f32 not above / not below a double
+float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -HUGE_VALF) : f; }
+float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, HUGE_VALF) : f; }
+
+// The wide node for binary node `ref`: its two children, the one with the largest box replaced by its own
+// two children until there are four (or only leaves are left).  32 words: lo.x[4] lo.y[4] lo.z[4] hi.x[4]
+// hi.y[4] hi.z[4] (f32, rounded outwards), the four references (NONE: no child), four unused.
+// Returns the reference for the walk and reports the depth of the wide tree.
+uint32_t mesh_collapse(MeshBuild& out, uint32_t ref, int depth, int& max_depth) {
+    if (ref & BVH_LEAF) return ref;
+    max_depth = std::max(max_depth, depth + 1);
+    struct Kid { double lo[3], hi[3]; uint32_t ref; };
+    Kid kids[4];
+    int n = 0;
+    auto take = [&](uint32_t from, int slot) {
+        for (int c = 0; c < 2; c++) {
+            Kid k;
+            for (int q = 0; q < 3; q++) { k.lo[q] = out.bin[from].lo[c][q]; k.hi[q] = out.bin[from].hi[c][q]; }
+            k.ref = out.bin[from].c[c];
+            if (c == 0) kids[slot] = k; else kids[n++] = k;
+        }
+    };
+    n = 1;
+    take(ref, 0);
+    while (n < 4) {
+        int widest = -1;
+        for (int k = 0; k < n; k++)
+            if (!(kids[k].ref & BVH_LEAF) && (widest < 0 || half_area(kids[k].lo, kids[k].hi) > half_area(kids[widest].lo, kids[widest].hi)))
+                widest = k;
+        if (widest < 0) break;
+        take(kids[widest].ref, widest);
+    }
+    const size_t node = out.nodes.size() / 32;
+    out.nodes.resize(out.nodes.size() + 32, 0.0f);
+    uint32_t refs[4] = {NONE, NONE, NONE, NONE};
+    for (int k = 0; k < n; k++) refs[k] = mesh_collapse(out, kids[k].ref, depth + 1, max_depth);
+    float* nd = &out.nodes[node * 32];
+    for (int k = 0; k < n; k++)
+        for (int q = 0; q < 3; q++) {
+            nd[q * 4 + k] = round_down(kids[k].lo[q]);
+            nd[12 + q * 4 + k] = round_up(kids[k].hi[q]);
+        }
+    std::memcpy(nd + 24, refs, sizeof refs);
     return (uint32_t)node;
 }
 
@@ -2719,7 +2833,9 @@ struct rt_scene {
     int device = 0;
     Workspace ws[MAX_STREAMS];
     int n_streams = 2;
-    int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane, 3: the reference's walk
+    int traversal = 0;                  // 0: by tree size, 1: the wave walks together, 2: lane by lane, 3: the reference's walk,
+                                        // 4: the wave together, meshes lane by lane
+    uint32_t mesh_units = 0;            // units inside meshes that have a hierarchy of their own
     uint32_t grid_blocks = 0;           // blocks of every level kernel (they stride over the rays); 0: see level_grid
     double* stage_rgb = nullptr;        // device staging for host outputs
     uint8_t* stage_rgb8 = nullptr;
@@ -2829,7 +2945,16 @@ struct FirstLevel {   // where the first level's rays come from
 // the tree is walked lane by lane: there the deep levels hold few rays with long walks, and a
 // shadow walk behind each of them doubles the serial chain, while k_shadow runs all the chunk's
 // shadow rays side by side.
-bool uses_lane_walk(const rt_scene* s) { return s->traversal == 2 || (s->traversal == 0 && s->dev.n_units > PER_LANE_MIN_UNITS); }
+// 0: the wave walks the tree together; 1: every lane on its own; 2: the wave together down to the meshes, every
+// lane on its own inside them (trees that are small once their meshes are set aside)
+int walk_mode(const rt_scene* s) {
+    if (s->traversal == 1 || s->traversal == 3) return 0;
+    if (s->traversal == 2) return 1;
+    if (s->traversal == 4) return 2;
+    if (s->dev.n_units <= PER_LANE_MIN_UNITS) return 0;
+    return s->mesh_units > 0 && s->dev.n_units - s->mesh_units <= PER_LANE_MIN_UNITS ? 2 : 1;
+}
+bool uses_lane_walk(const rt_scene* s) { return walk_mode(s) != 0; }  // lanes of a wave walk (partly) on their own
 bool reference_walk(const rt_scene* s) { return s->traversal == 3; }  // no device-only shortcut anywhere
 bool fused_shadows(const rt_scene* s, bool per_lane) { return !s->has_area && !per_lane && !reference_walk(s); }
 // Blocks per level kernel.  A k_trace block is 4 waves of the 16 a CU holds, so 1024 blocks are one
@@ -2843,23 +2968,29 @@ uint32_t level_grid(const rt_scene* s, bool trace) {
     if (s->n_streams > 1 && !uses_lane_walk(s)) return trace ? 1024u : 2048u;
     return 4096u;
 }
-template <bool PRIMARY, bool HAS_CSG, bool PER_LANE>
+template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool HYBRID>
 void launch_trace(rt_scene* s, dim3 grid, hipStream_t st, const LevelArgs& A) {
-    if constexpr (HAS_CSG && !PER_LANE) {
+    if constexpr (HAS_CSG && !PER_LANE && !HYBRID) {
         if (reference_walk(s)) {
             hipLaunchKernelGGL((k_trace<PRIMARY, true, false, false, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
             return;
         }
     }
-    if (fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
-    else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, PER_LANE, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    if constexpr (HYBRID) {
+        hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, false, false, true, false, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    } else if constexpr (PER_LANE) {
+        hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, true, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    } else {
+        if (fused_shadows(s, false)) hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, false, true>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+        else hipLaunchKernelGGL((k_trace<PRIMARY, HAS_CSG, false, false>), grid, dim3(TRACE_BLOCK), 0, st, s->dev, A);
+    }
 }
 
 // Queue every kernel of one batch of first-level rays on the workspace's stream: the levels, the
 // shadow rays, then the colours from the deepest level up (level 0 writes the outputs).  Nothing
 // here waits for the GPU unless the scene has an area light (its rng order needs the level sizes
 // on the host).  `slot` selects the workspace's ChunkStatus entry and event quadruple.
-template <bool HAS_CSG, bool PER_LANE>
+template <bool HAS_CSG, bool PER_LANE, bool HYBRID = false>
 int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& first, uint32_t depth, double* out_rgb,
                 uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot, bool big) {
     hipStream_t st = w.stream;
@@ -2895,9 +3026,9 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
             else
                 hipLaunchKernelGGL((k_trace<false, true, true, false, true, true>), dim3(BIG_GRID), dim3(TRACE_BLOCK), 0, st, big_dev, A);
         } else if (first.primary && level == 0)
-            launch_trace<true, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
+            launch_trace<true, HAS_CSG, PER_LANE, HYBRID>(s, grid_trace, st, A);
         else
-            launch_trace<false, HAS_CSG, PER_LANE>(s, grid_trace, st, A);
+            launch_trace<false, HAS_CSG, PER_LANE, HYBRID>(s, grid_trace, st, A);
     }
     tot.trace_launches += n_levels;
     HIP_TRY(hipGetLastError());
@@ -2958,13 +3089,16 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
         hipLaunchKernelGGL((k_shadow<true, true, true, true>), dim3(BIG_GRID), block, 0, st, big_dev, A);
         shadows_queued = true;
     }
-    if constexpr (HAS_CSG && !PER_LANE) {
+    if constexpr (HAS_CSG && !PER_LANE && !HYBRID) {
         if (!shadows_queued && reference_walk(s)) {
             hipLaunchKernelGGL((k_shadow<true, false, false>), grid, block, 0, st, s->dev, A);
             shadows_queued = true;
         }
     }
-    if (!shadows_queued && !fused_shadows(s, PER_LANE)) hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
+    if (!shadows_queued && !fused_shadows(s, PER_LANE || HYBRID)) {
+        if constexpr (HYBRID) hipLaunchKernelGGL((k_shadow<HAS_CSG, false, true, false, true>), grid, block, 0, st, s->dev, A);
+        else hipLaunchKernelGGL((k_shadow<HAS_CSG, PER_LANE>), grid, block, 0, st, s->dev, A);
+    }
     if (timed) HIP_TRY(hipEventRecord(w.ev[4 * slot + 2], st));
     for (int level = (int)n_levels - 1; level >= 0; level--) {
         A.level = (uint32_t)level;
@@ -2981,14 +3115,16 @@ int queue_chunk(rt_scene* s, Workspace& w, LevelArgs base, const FirstLevel& fir
 
 int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const FirstLevel& first, uint32_t depth,
                          double* out_rgb, uint8_t* out_rgb8, size_t out_offset, size_t slot, RunTotals& tot, bool big = false) {
-    const bool per_lane = uses_lane_walk(s);
+    const int mode = walk_mode(s);
     if (big) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, true);
     if (reference_walk(s)) return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
     if (s->has_csg) {
-        if (per_lane) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+        if (mode == 2) return queue_chunk<true, false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+        if (mode == 1) return queue_chunk<true, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
         return queue_chunk<true, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
     }
-    if (per_lane) return queue_chunk<false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+    if (mode == 2) return queue_chunk<false, false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
+    if (mode == 1) return queue_chunk<false, true>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
     return queue_chunk<false, false>(s, w, base, first, depth, out_rgb, out_rgb8, out_offset, slot, tot, false);
 }
 
@@ -3351,6 +3487,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     std::vector<uint32_t> parent_unit((size_t)units + 4, NONE);
     MeshBuild meshes;
     meshes.stream = stream.data();
+    uint32_t mesh_units = 0;
     {
         for (uint32_t i = 0; i < d->n_nodes; i++) {
             uint32_t pu = parent_node[i] == NONE ? NONE : unit_of[parent_node[i]];
@@ -3394,13 +3531,26 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
                     mt.lo[a] = std::min(p0, std::min(p1, p2));
                     mt.hi[a] = std::max(p0, std::max(p1, p2));
                     mt.c[a] = 0.5 * (mt.lo[a] + mt.hi[a]);
-                    finite = finite && std::isfinite(mt.lo[a]) && std::isfinite(mt.hi[a]);
+                    finite = finite && std::fabs(mt.lo[a]) < 1e30 && std::fabs(mt.hi[a]) < 1e30;  // also false for NaN
                 }
                 tris.push_back(mt);
             }
             if (!finite) continue;
+            // the binary tree first, then four children a node; a hierarchy too deep for the walk's stack (three
+            // entries a level) or with coordinates beyond f32 is dropped and the mesh walked like any group
+            meshes.bin.clear();
+            const size_t nodes_before = meshes.nodes.size(), tris_before = meshes.tris.size();
+            const uint32_t bin_root = mesh_build(tris, 0, tris.size(), 0, meshes);
+            int wide_depth = 0;
+            const uint32_t wide_root = mesh_collapse(meshes, bin_root, 0, wide_depth);
+            if (3 * wide_depth + 1 > BVH_STACK) {
+                meshes.nodes.resize(nodes_before);
+                meshes.tris.resize(tris_before);
+                continue;
+            }
             uint32_t* rec = &stream[(size_t)unit_of[i] * 16];
-            rec[2] = mesh_build(tris, 0, tris.size(), 0, meshes);
+            rec[2] = wide_root;
+            mesh_units += rec[1] - unit_of[i] - 1;
             rec[3] = matrix[i];
             rec[0] |= MESH_BIT;
             bool all_cast = true, none_cast = true;
@@ -3429,6 +3579,7 @@ int rt_scene_create(const rt_scene_desc* d, rt_scene** out) {
     auto* s = new rt_scene();
     (void)hipGetDevice(&s->device);
     s->has_csg = has_csg;
+    s->mesh_units = mesh_units;
     s->csg_list_bound = csg_list_bound;
     s->world_list_bound = world_list_bound;
     s->has_area = has_area;
@@ -3559,7 +3710,7 @@ int rt_set_option(rt_scene* s, int option, uint64_t value) {
             }
             return RT_OK;
         case RT_OPT_TRAVERSAL:
-            if (value > 3) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave), 2 (lane) or 3 (reference)");
+            if (value > 4) return fail(RT_ERR_INVALID, "traversal must be 0 (auto), 1 (wave), 2 (lane), 3 (reference) or 4 (wave, meshes by lane)");
             s->traversal = (int)value;
             return RT_OK;
         case RT_OPT_MIN_CHUNKS:

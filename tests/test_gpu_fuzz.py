@@ -258,7 +258,7 @@ def test_random_scene_every_walk_equals_the_reference_walk(seed):
         # a NaN distance (the reference panics while sorting it); lists past the fast kernels' bounds take the slow path
         assert e.code == ra.RT_ERR_NAN, text
         pytest.skip("reference walk: %s" % e)
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 4):
         got, st = render(text, mode, seed, depth)
         same = np.array_equal(got.pixels.view(np.uint64), ref.pixels.view(np.uint64))
         assert same, "traversal %d differs in %d pixels\n%s" % (mode, int((got.pixels != ref.pixels).any(axis=2).sum()), text)
@@ -357,7 +357,7 @@ def test_lists_past_the_fast_kernels_take_the_slow_path(name):
     text = long_list_scenes()[name]
     o = ol.OracleScene.from_text(text, 1.0, 0, ROOT)
     want = o.render_rows(6, o.row_seeds(), threads=16)
-    for mode in (0, 2, 3):
+    for mode in (0, 2, 3, 4):
         got, st = render(text, mode, 0, 6)
         if mode == 3:  # the reference's walk records every crossing; the culling walks may stay below the bounds
             assert st["big_chunks"] >= 1, (name, mode, st)

@@ -166,13 +166,17 @@ def test_both_tree_walks_give_the_same_image(scene, scale, depth):
     The lane-by-lane walk goes through a mesh by its own hierarchy and so counts fewer tests:
     the work counters only have to agree for scenes without a mesh."""
     frames = []
-    for mode in (1, 2):
+    for mode in (1, 2, 4):
         g, _ = pair(scene, scale)
         g.set_option(ra.OPT_TRAVERSAL, mode)
         seeds = g.row_seeds()
         c, st = g.render(depth, seeds)
         frames.append((c, st))
-    (a, sa), (b, sb) = frames
+    (a, sa), (b, sb), (h, sh) = frames
+    # the hybrid walk: the wave's walk outside the meshes, the lane walk's inside them
+    assert np.array_equal(h.pixels.view(np.uint64), a.pixels.view(np.uint64))
+    for key in ("secondary_rays", "shadow_rays", "shade_hits"):
+        assert sh[key] == sa[key], key
     assert np.array_equal(a.pixels.view(np.uint64), b.pixels.view(np.uint64))
     assert np.array_equal(a.rgb8, b.rgb8)
     has_mesh = scene in ("scenes/chapter15.yaml", "scenes/bounding-box.yaml")
@@ -312,6 +316,7 @@ def test_mesh_hierarchy_respects_the_stored_boxes(scene, scale, root_depth):
     a0, _ = frame(d, 3)
     b0, _ = frame(d, 2)
     assert np.array_equal(a0.view(np.uint64), b0.view(np.uint64))
+    assert np.array_equal(a0.view(np.uint64), frame(d, 4)[0].view(np.uint64))
     # shrink the box of every group below a mesh's root
     kind, skip = d["node_kind"], d["node_skip"]
     depth_of = np.zeros(len(kind), dtype=np.int64)
@@ -336,6 +341,7 @@ def test_mesh_hierarchy_respects_the_stored_boxes(scene, scale, root_depth):
     b1, sb = frame(d2, 2)
     assert np.array_equal(a1.view(np.uint64), b1.view(np.uint64))
     assert sa["shade_hits"] == sb["shade_hits"] and sa["secondary_rays"] == sb["secondary_rays"]
+    assert np.array_equal(a1.view(np.uint64), frame(d2, 4)[0].view(np.uint64))
     assert not np.array_equal(a0, a1)
 
 
@@ -389,7 +395,7 @@ def test_coincident_triangles_resolve_like_the_reference_list():
     lm[odd] = len(d["material"])
     d2["leaf_material"] = lm
     frames = []
-    for mode in (3, 2, 1):
+    for mode in (3, 2, 1, 4):
         h, keep = _create_from_arrays(d2)
         assert lib.rt_set_option(h, ra.OPT_TRAVERSAL, mode) == 0
         rgb = np.zeros((g.height, g.width, 3))

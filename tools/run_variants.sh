@@ -6,6 +6,6 @@ cp raytracer_amd/librt_hip.so /tmp/librt_hip_orig.so
 for name in "$@"; do
   cp variants/librt_hip_$name.so raytracer_amd/librt_hip.so
   echo "== $name" >> gpurun_out/variants.log
-  timeout -k 10 200 python3 bench.py $args --no-cpu-baseline 2>/dev/null | python3 tools/bench_line.py >> gpurun_out/variants.log || { echo "FAILED $name" >> gpurun_out/variants.log; break; }
+  timeout -k 10 200 python3 bench.py $args --no-cpu-baseline --no-host-frames 2>/dev/null | python3 tools/bench_line.py >> gpurun_out/variants.log || { echo "FAILED $name" >> gpurun_out/variants.log; break; }
 done
 cp /tmp/librt_hip_orig.so raytracer_amd/librt_hip.so
