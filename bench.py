@@ -74,11 +74,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # RT_BENCH_REHEARSAL=1: every rank on GPU 0 with gloo between them - a rehearsal of the N>1 code path on a
+    # box with one GPU (RCCL refuses two ranks on one device); never a measurement
+    rehearsal = world > 1 and os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     ra.init(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
 
     scene_file, scale, depth = WORKLOADS[args.workload]
     if args.scale is not None:
@@ -131,8 +136,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # whole-job numbers: max time over ranks, rays summed over ranks
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    rays = torch.tensor([stats["primary_rays"], stats["secondary_rays"], stats["shadow_rays"]], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([stats["primary_rays"], stats["secondary_rays"], stats["shadow_rays"]], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -164,10 +170,17 @@ def main():
                 % (multi.BLOCK_ROWS, world),
             },
             "frame_ms": ms_per_step,
+            **({"rehearsal": "all ranks on GPU 0, gloo between them: exercises the N>1 code path, measures nothing"} if rehearsal else {}),
             "rays": {"primary": primary, "secondary": secondary, "shadow": shadow,
                      "all_mrays_per_s": (primary + secondary + shadow) / (ms_per_step * 1e-3) / 1e6},
             "published_cpu_reference": {"rayon_s": 71.55, "single_thread_s": 264.26, "hardware": "unstated (README.md:120-126)"},
         }
+        if rehearsal:
+            # the assembled frame against one whole-frame render on this rank
+            whole = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+            scene.render_device(depth, seeds, None, 0, whole.data_ptr())
+            torch.cuda.synchronize()
+            out["rehearsal_frame_equals_single_render"] = bool(torch.equal(whole, frame))
         if world == 1:
             # Kernel times: with two chunks in flight the kernels of different chunks share the GPU and their
             # event spans overlap, so the per-kernel figures come from one extra frame rendered with a single

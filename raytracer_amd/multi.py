@@ -32,6 +32,12 @@ def gather_rows(local, height, rank, world, block_rows=BLOCK_ROWS, dst=0):
     """
     if world == 1:
         return local
+    # gloo only moves host memory reliably: a rehearsal of the multi-rank path on GPUs without RCCL (ranks that
+    # share one GPU) stages through the host, with synchronous copies
+    device = local.device
+    via_host = dist.get_backend() == "gloo" and local.is_cuda
+    if via_host:
+        local = local.cpu()
     pad_rows = max_local_rows(height, world, block_rows)
     padded = local
     if local.shape[0] != pad_rows:
@@ -48,4 +54,4 @@ def gather_rows(local, height, rank, world, block_rows=BLOCK_ROWS, dst=0):
     for r in range(world):
         rows = torch.as_tensor(local_rows(height, partition_for(r, world, block_rows)), device=local.device)
         frame.index_copy_(0, rows, parts[r][: rows.shape[0]])
-    return frame
+    return frame.to(device) if via_host else frame
