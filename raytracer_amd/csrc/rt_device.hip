@@ -2156,27 +2156,44 @@ __global__ void k_chunk_begin(LevelState* levels, uint32_t n_entries, uint32_t n
 // STAT_SHARDS threads.
 __global__ __launch_bounds__(STAT_SHARDS) void k_chunk_end(const LevelState* levels, uint32_t n_levels,
                                                            const Counters* counters, StatShard* stats, ChunkStatus* out) {
-    __shared__ unsigned long long sums[8];
-    if (threadIdx.x < 8) sums[threadIdx.x] = 0ull;
-    __syncthreads();
+    __shared__ unsigned long long sums[STAT_SHARDS / 64][8];
+    __shared__ uint32_t used_by_wave[STAT_SHARDS / 64];
     StatShard* st = stats + threadIdx.x;
-    atomicAdd(&sums[0], st->secondary); atomicAdd(&sums[1], st->shadow); atomicAdd(&sums[2], st->shade);
-    atomicAdd(&sums[3], st->flop_trace); atomicAdd(&sums[4], st->flop_shadow); atomicAdd(&sums[5], st->flop_light);
-    atomicAdd(&sums[6], st->mesh_nodes); atomicAdd(&sums[7], st->mesh_tris);
+    unsigned long long v[8] = {st->secondary, st->shadow, st->shade, st->flop_trace, st->flop_shadow, st->flop_light,
+                               st->mesh_nodes, st->mesh_tris};
     st->secondary = 0; st->shadow = 0; st->shade = 0; st->flop_trace = 0; st->flop_shadow = 0; st->flop_light = 0;
     st->mesh_nodes = 0; st->mesh_tris = 0;
+    uint32_t used = 0;  // one more than the deepest level that held a ray
+    for (uint32_t l = threadIdx.x; l < n_levels; l += STAT_SHARDS)
+        if (levels[l].n) used = l + 1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[k], off, WAVE), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[k] >> 32), off, WAVE);
+            v[k] += ((unsigned long long)hi << 32) | lo;
+        }
+        used = max(used, (uint32_t)__shfl_xor((int)used, off, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 8; k++) sums[threadIdx.x >> 6][k] = v[k];
+        used_by_wave[threadIdx.x >> 6] = used;
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    uint32_t used = 0;
-    for (uint32_t l = 0; l < n_levels; l++)
-        if (levels[l].n) used = l + 1;
+    unsigned long long total[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    used = 0;
+    for (uint32_t w = 0; w < STAT_SHARDS / 64; w++) {
+        for (int k = 0; k < 8; k++) total[k] += sums[w][k];
+        used = max(used, used_by_wave[w]);
+    }
     out->error = counters->error;
     out->total_recs = levels[n_levels].base;
     out->levels = used;
     out->pad = 0;
-    out->secondary = sums[0]; out->shadow = sums[1]; out->shade = sums[2];
-    out->flop_trace = sums[3]; out->flop_shadow = sums[4]; out->flop_light = sums[5];
-    out->mesh_nodes = sums[6]; out->mesh_tris = sums[7];
+    out->secondary = total[0]; out->shadow = total[1]; out->shade = total[2];
+    out->flop_trace = total[3]; out->flop_shadow = total[4]; out->flop_light = total[5];
+    out->mesh_nodes = total[6]; out->mesh_tris = total[7];
 }
 
 // ---- deferred shading order (area lights): the reference consumes one rng stream per row, pixel
@@ -2804,7 +2821,7 @@ struct Workspace {
     size_t levels_cap = 0;
     Counters* counters = nullptr;
     StatShard* stats = nullptr;
-    ChunkStatus* status = nullptr;      // one entry per chunk queued on this workspace
+    ChunkStatus* status = nullptr;      // one entry per chunk queued on this workspace (page-locked host memory)
     size_t status_cap = 0;
     std::vector<hipEvent_t> ev;         // four per queued chunk: start, traced, shadowed, shaded
     // rng order (area lights)
@@ -2880,8 +2897,16 @@ int ensure_workspace(rt_scene* s, Workspace& w, size_t chunk_px, size_t n_first,
         HIP_TRY(hipStreamSynchronize(w.stream));
     int rc = grow(&w.intensity, &w.intensity_cap, w.rec_cap * s->dev.n_lights);
     if (rc == RT_OK) rc = grow(&w.levels, &w.levels_cap, (size_t)depth + 2);
-    if (rc == RT_OK) rc = grow(&w.status, &w.status_cap, std::max<size_t>(n_chunks, 16));
     if (rc != RT_OK) return rc;
+    if (n_chunks > w.status_cap) {
+        // page-locked host memory the device writes straight into: the host reads a chunk's status after the
+        // stream has drained, with no copy to wait for
+        if (w.status) HIP_TRY(hipHostFree(w.status));
+        w.status = nullptr; w.status_cap = 0;
+        const size_t cap = std::max<size_t>(n_chunks, 16);
+        HIP_TRY(hipHostMalloc((void**)&w.status, cap * sizeof(ChunkStatus), hipHostMallocDefault));
+        w.status_cap = cap;
+    }
     while (w.ev.size() < 4 * n_chunks) {
         hipEvent_t e = nullptr;
         HIP_TRY(hipEventCreate(&e));
@@ -2892,9 +2917,10 @@ int ensure_workspace(rt_scene* s, Workspace& w, size_t chunk_px, size_t n_first,
 
 void free_workspace(Workspace& w) {
     if (w.stream) (void)hipStreamSynchronize(w.stream);
-    void* bufs[] = {w.rec_slab, w.intensity, w.levels, w.counters, w.stats, w.status,
+    void* bufs[] = {w.rec_slab, w.intensity, w.levels, w.counters, w.stats,
                     w.rng_states, w.pixel_base, w.row_total, w.row_base, w.big_slab};
     for (void* p : bufs) if (p) (void)hipFree(p);
+    if (w.status) (void)hipHostFree(w.status);
     for (auto& e : w.ev) if (e) (void)hipEventDestroy(e);
     if (w.stream) (void)hipStreamDestroy(w.stream);
     w = Workspace{};
@@ -3132,8 +3158,8 @@ int queue_chunk_dispatch(rt_scene* s, Workspace& w, const LevelArgs& base, const
 int collect(Workspace& w, size_t n_slots, std::vector<ChunkStatus>& out, RunTotals& tot) {
     out.assign(n_slots, ChunkStatus{});
     if (n_slots == 0) return RT_OK;
-    HIP_TRY(hipMemcpyAsync(out.data(), w.status, n_slots * sizeof(ChunkStatus), hipMemcpyDeviceToHost, w.stream));
     HIP_TRY(hipStreamSynchronize(w.stream));
+    std::memcpy(out.data(), w.status, n_slots * sizeof(ChunkStatus));  // page-locked host memory (ensure_workspace)
     float ms = 0;
     for (size_t k = 0; k < n_slots; k++) {
         HIP_TRY(hipEventElapsedTime(&ms, w.ev[4 * k + 0], w.ev[4 * k + 1]));
@@ -3810,8 +3836,21 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
     // number of streams, so that the streams end together.  The record arrays of all workspaces
     // may take 80 % of the device's memory, and 90 % of what is free of it.
     const int n_ws = std::max(1, std::min(s->n_streams, MAX_STREAMS));
+    const size_t frame_px = (size_t)rows * W;
+    uint32_t chunk_rows = 8;
+    auto plan = [&](size_t chunk_px) {
+        size_t n_chunks = (frame_px + chunk_px - 1) / chunk_px;
+        if (frame_px >= ((size_t)2 << 20)) n_chunks = std::max<size_t>(n_chunks, s->min_chunks);
+        if (n_chunks > 1) n_chunks = (n_chunks + n_ws - 1) / n_ws * n_ws;
+        chunk_rows = std::max(8u, (uint32_t)(((rows + n_chunks - 1) / n_chunks + 7) & ~(size_t)7));
+    };
     size_t chunk_px = std::max<size_t>(s->chunk_pixels, 64);
-    {
+    plan(chunk_px);
+    // the device's memory is only asked about when a workspace would have to grow for this plan
+    bool grows = false;
+    for (int k = 0; k < n_ws; k++)
+        grows = grows || s->ws[k].rec_cap < std::max<size_t>(s->recs_per_pixel * (size_t)std::min(chunk_rows, rows) * W, 4096);
+    if (grows) {
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess && mem_total) {
             const size_t per_rec = REC_BYTES + 8 * (size_t)s->dev.n_lights, per_px = s->recs_per_pixel * per_rec;
@@ -3819,13 +3858,9 @@ int rt_render(rt_scene* s, const rt_camera* cam, uint32_t depth, const uint64_t*
             for (int k = 0; k < n_ws; k++) held += s->ws[k].rec_cap * per_rec;
             const size_t budget = std::min(mem_total / 10 * 8, (mem_free + held) / 10 * 9);
             chunk_px = std::max<size_t>(std::min(chunk_px, budget / ((size_t)n_ws * per_px)), (size_t)8 * W);
+            plan(chunk_px);
         }
     }
-    const size_t frame_px = (size_t)rows * W;
-    size_t n_chunks = (frame_px + chunk_px - 1) / chunk_px;
-    if (frame_px >= ((size_t)2 << 20)) n_chunks = std::max<size_t>(n_chunks, s->min_chunks);
-    if (n_chunks > 1) n_chunks = (n_chunks + n_ws - 1) / n_ws * n_ws;
-    uint32_t chunk_rows = std::max(8u, (uint32_t)(((rows + n_chunks - 1) / n_chunks + 7) & ~(size_t)7));
     struct Job { uint32_t r0, nr; bool big; };  // big: rendered again with the lists in global memory
     struct Arrival { hipEvent_t copied; size_t at, n; };  // a chunk's outputs: first element and element count
     std::vector<Job> pending;
