@@ -25,6 +25,18 @@ def max_local_rows(height, world, block_rows=BLOCK_ROWS):
     return max(len(local_rows(height, partition_for(r, world, block_rows))) for r in range(world))
 
 
+_row_index_cache = {}
+
+
+def _row_indices(height, world, block_rows, device):
+    """Per rank, the frame rows it renders, as an index tensor on `device` (built once per frame shape)."""
+    key = (height, world, block_rows, str(device))
+    if key not in _row_index_cache:
+        _row_index_cache[key] = [torch.as_tensor(local_rows(height, partition_for(r, world, block_rows)), device=device)
+                                 for r in range(world)]
+    return _row_index_cache[key]
+
+
 def gather_rows(local, height, rank, world, block_rows=BLOCK_ROWS, dst=0):
     """Gather per-rank row tensors (rows_local, width, C) to `dst` and restore row order.
 
@@ -51,7 +63,6 @@ def gather_rows(local, height, rank, world, block_rows=BLOCK_ROWS, dst=0):
     if rank != dst:
         return None
     frame = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        rows = torch.as_tensor(local_rows(height, partition_for(r, world, block_rows)), device=local.device)
+    for r, rows in enumerate(_row_indices(height, world, block_rows, local.device)):
         frame.index_copy_(0, rows, parts[r][: rows.shape[0]])
     return frame.to(device) if via_host else frame
