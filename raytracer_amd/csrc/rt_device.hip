@@ -19,8 +19,9 @@
 //
 // The tree is a depth-first stream of 64-byte units with skip links.  Small trees are walked by
 // the 64 lanes of a wave together (position in an SGPR, node data through scalar loads, a
-// per-lane "skip until" for rejected subtrees); large ones lane by lane, and a mesh inside them
-// by a hierarchy of its own (mesh_walk).  Intersections arrive in the reference's insertion
+// per-lane "skip until" for rejected subtrees); large ones lane by lane; a mesh is walked lane by
+// lane in either case, by a hierarchy of its own (mesh_walk), so a tree that is small apart from
+// its meshes takes the wave's walk down to them.  Intersections arrive in the reference's insertion
 // order (ties inside a mesh go to the lower stream position, which is the same thing), so a
 // strict `<` against the running best reproduces its stable sort + first-positive-t rule
 // without sorting.
@@ -30,6 +31,9 @@
 // depend on the rng), a few small passes number the shade points of each row in the reference's
 // order and step the row's generator to each of them, then k_shadow and k_shade give every
 // point its own generator state.
+//
+// A ray keeps its csg and candidate lists in fixed-size fast memory; a chunk in which some ray
+// needs more is rendered again by variants of the kernels that keep the lists in global memory.
 //
 // All arithmetic is f64 with contraction off; expressions keep the operand order of the
 // reference (cited per function, paths relative to the reference's src/).
