@@ -196,6 +196,11 @@ def main():
             flop = stats["flop_trace"] + (stats["flop_shadow"] if fused else 0)
             ms_k = stats["ms_trace"]
             launches = stats["trace_launches"]
+            dominant = "k_trace"
+            if not fused and stats["ms_shadow"] > ms_k:
+                # the shadow rays are a kernel of their own and take longer than the tracing (area lights: a hundred
+                # shadow rays per shade point): the roofline is that kernel's, one launch per chunk
+                dominant, flop, ms_k, launches = "k_shadow", stats["flop_shadow"], stats["ms_shadow"], stats["chunks"]
             achieved = flop / (ms_k * 1e-3) / 1e12 if ms_k > 0 else 0.0
             # algorithmic bytes of the record arrays (8-byte and 4-byte columns, one element per ray):
             #   every ray: hit_pos written once, read by k_shadow and k_shade (12 B)
@@ -212,10 +217,11 @@ def main():
             out["roofline"] = {
                 "bound": "valu_fp64",
                 "kernel": "k_trace (closest hit + n1/n2 + spawn" + (" + shadow rays" if fused else "") +
-                          "; one launch per recursion level and chunk)",
-                "measured": "HIP events on the launch stream around each chunk's k_trace launches, in one extra "
-                            "single-stream frame after the timed region" if args.streams != 1 else
-                            "HIP events on the launch stream around each chunk's k_trace launches, last timed frame",
+                          "; one launch per recursion level and chunk)" if dominant == "k_trace" else
+                          "k_shadow (one closest-hit walk per light sample of every shade point; one launch per chunk)",
+                "measured": "HIP events on the launch stream around each chunk's %s launches, in one extra "
+                            "single-stream frame after the timed region" % dominant if args.streams != 1 else
+                            "HIP events on the launch stream around each chunk's %s launches, last timed frame" % dominant,
                 "single_stream_frame_ms": stats["ms_total"],
                 "timed_region": timed_spans,
                 "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -227,6 +233,7 @@ def main():
                 "kernel_ms_per_frame": ms_k,
                 "traffic": None,
                 "other_kernels": {
+                    "k_trace": {"ms_per_frame": stats["ms_trace"], "algorithmic_flop_per_frame": stats["flop_trace"]},
                     "k_shadow": ({"fused_into": "k_trace", "algorithmic_flop_per_frame": stats["flop_shadow"]} if fused else
                                  {"ms_per_frame": stats["ms_shadow"], "algorithmic_flop_per_frame": stats["flop_shadow"]}),
                     "k_shade": {"ms_per_frame": stats["ms_shade"], "algorithmic_flop_per_frame": stats["flop_light"]},
