@@ -71,6 +71,9 @@ constexpr uint32_t SPAWN_BINS = 32;  // groups the rays a block spawns in one st
 #ifndef TRACE_WAVES
 #define TRACE_WAVES 4     // occupancy the compiler must reach for k_trace (waves per SIMD; csg variants: 2)
 #endif
+#ifndef CSG_WAVES
+#define CSG_WAVES 4       // the same for the walking kernels of scenes with a csg (measured on chapter16: 2 -> 4 is +50 %, spills and all)
+#endif
 #ifndef SHADOW_WAVES
 #define SHADOW_WAVES 5    // the same for k_shadow
 #endif
@@ -1707,7 +1710,7 @@ DEV V3 combine(V3 surface, V3 reflected, V3 refracted, double m_reflective, doub
 // start on, reflected / refracted), so that the next level's waves hold rays that meet the same
 // objects and a test culled for one lane is more often culled for all 64.
 template <bool PRIMARY, bool HAS_CSG, bool PER_LANE, bool FUSED, bool CULL = true, bool BIG = false, bool HYBRID = false>
-__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : (PER_LANE || HYBRID) ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? CSG_WAVES : (PER_LANE || HYBRID) ? LANE_TRACE_WAVES : TRACE_WAVES) void k_trace(DevScene S, LevelArgs A) {
     constexpr bool LANES_DIVERGE = PER_LANE || HYBRID;  // walks of very different length side by side in one wave
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -1968,7 +1971,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, HAS_CSG ? 2 : (PER_LANE || HYBRID) ? L
 // The shadow rays of every record of a chunk, for scenes whose lights need the rng order of the
 // whole chunk first (area lights); otherwise k_trace casts them itself.
 template <bool HAS_CSG, bool PER_LANE, bool CULL = true, bool BIG = false, bool HYBRID = false>
-__global__ __launch_bounds__(256, HAS_CSG ? 2 : (PER_LANE || HYBRID) ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
+__global__ __launch_bounds__(256, HAS_CSG ? CSG_WAVES : (PER_LANE || HYBRID) ? LANE_SHADOW_WAVES : SHADOW_WAVES) void k_shadow(DevScene S, LevelArgs A) {
     constexpr bool LANES_DIVERGE = PER_LANE || HYBRID;
     const uint32_t lane = threadIdx.x & 63;
     if (A.counters->error & 1u) return;
