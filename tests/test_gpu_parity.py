@@ -12,7 +12,7 @@ from golden_scenes import GOLDEN, SCALE, SEED
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-REL_TOL = 1e-9  # linear colour tolerance of BASELINE.json's north_star
+REL_TOL = 1e-9  # tolerance on linear colour (relative): the 8-bit image must be identical, f64 may differ by rounding order only
 
 
 def pair(scene, scale, seed=0):
@@ -29,7 +29,7 @@ def compare(canvas, ref):
     return bad8, float(rel.max())
 
 
-# scene, scale, depth: every BASELINE config at a size the oracle renders in seconds, plus the other scene files;
+# scene, scale, depth: every benchmarked configuration at a size the oracle renders in seconds, plus the other scene files;
 # odd scales exercise widths that are not multiples of the 8x8 tile
 CASES = [
     ("scenes/chapter6.yaml", 0.5, 5), ("scenes/chapter6.yaml", 2.0, 5), ("scenes/chapter8.yaml", 0.33, 5),
