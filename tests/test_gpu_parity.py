@@ -259,6 +259,23 @@ def test_error_paths():
         ol.OracleScene.from_file(os.path.join(ROOT, "scenes", "chapter8.yaml")).colour_at(ray, 5)
 
 
+def test_a_failing_frame_leaves_the_scene_usable():
+    """A camera with a NaN in its matrix makes every distance NaN (the reference panics while sorting them):
+    rt_render reports it after all its streams have drained, and the same scene then renders as before."""
+    g, _ = pair("scenes/chapter11.yaml", 0.4)
+    seeds = g.row_seeds()
+    g.set_option(ra.OPT_CHUNK_PIXELS, 16 * g.width)   # several chunks on two streams
+    good, _ = g.render(6, seeds)
+    lib = ra.hip_lib()
+    cam = ra.CameraDesc.from_buffer_copy(g.camera())
+    cam.inv[5] = float("nan")
+    rgb = np.zeros((g.height, g.width, 3))
+    rc = lib.rt_render(g.upload(), C.byref(cam), 6, None, None, rgb.ctypes.data_as(C.c_void_p), None, 0, None)
+    assert rc == ra.RT_ERR_NAN, lib.rt_last_error().decode()
+    again, _ = g.render(6, seeds)
+    assert np.array_equal(again.pixels.view(np.uint64), good.pixels.view(np.uint64))
+
+
 def _create_from_arrays(d):
     """rt_scene_create straight from (possibly edited) rt_scene_desc arrays; returns (handle, keepalive)."""
     keep = {k: np.ascontiguousarray(v) for k, v in d.items() if isinstance(v, np.ndarray)}
